@@ -1,0 +1,176 @@
+/*
+ * specgpu.h -- C ABI of the MI355X-native spectrogram / PSD engine.
+ *
+ * This is the drop-in boundary for ONE path of GassiusODude/spectral_analyzer:
+ * sample reader -> (window) -> FFT -> |X| -> 20 log10 / Welch PSD, i.e. the code
+ * behind the Spectrogram and PSD views.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference repo,
+ * src/main/java/net/kcundercover/spectral_analyzer/...).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types, no exceptions.
+ *   - every call returns a spec_status; spec_last_error() gives the text.
+ *   - the caller owns every buffer it passes; the library owns only what lives
+ *     inside a spec_ctx (twiddle / window tables, staging and scratch memory).
+ *   - a spec_ctx is bound to one GPU and one HIP stream and is not re-entrant;
+ *     distinct contexts are independent (one per device / host thread).
+ *   - there is NO CPU backend: without a usable gfx950 device spec_create fails
+ *     with SPEC_EDEVICE.
+ *   - device-pointer calls are asynchronous on the context's stream; host-pointer
+ *     calls return after the results are in the caller's memory.
+ */
+#ifndef SPECGPU_H
+#define SPECGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPECGPU_VERSION_MAJOR 0
+#define SPECGPU_VERSION_MINOR 1
+
+typedef struct spec_ctx spec_ctx;
+
+typedef enum {
+    SPEC_OK = 0,
+    SPEC_EINVAL = 1,       /* bad argument (non power-of-two nfft, hop == 0, null pointer ...);
+                              Java: IllegalArgumentException (commons-math3 throws
+                              MathIllegalArgumentException for a bad length, SS:29) */
+    SPEC_ERANGE = 2,       /* byte range outside the buffer; Java: IndexOutOfBoundsException
+                              (the MappedByteBuffer getters at SS:44-57) */
+    SPEC_EDEVICE = 3,      /* HIP error / no gfx950 device */
+    SPEC_ENOMEM = 4,       /* host or device allocation failed */
+    SPEC_EUNSUPPORTED = 5  /* valid request the build does not implement yet */
+} spec_status;
+
+/* Sample formats.  SigMF strings are matched with startsWith exactly as
+ * SpectralService.java:35-38 / Global.java:67-79 do; the byte order follows
+ * SigMfHelper.java:87-91 (suffix "_le" -> little endian, anything else big). */
+typedef enum {
+    SPEC_DT_UNKNOWN = 0,   /* decodes to 0+0i -> flat -200 dB (SS:60-63) */
+    SPEC_DT_CU8 = 1,       /* (b & 0xFF - 127.5) / 128          SS:50-54 */
+    SPEC_DT_CI8 = 2,       /* b / 128                           SS:55-59 */
+    SPEC_DT_CI16_LE = 3,   /* getShort / 32768.0                SS:42-45 */
+    SPEC_DT_CI16_BE = 4,
+    SPEC_DT_CF32_LE = 5,   /* getFloat                          SS:46-49 */
+    SPEC_DT_CF32_BE = 6,
+    SPEC_DT_CF64_LE = 7,   /* getDouble at +0 / +8   ExtractDownConvertService.java:79-81 */
+    SPEC_DT_CF64_BE = 8
+} spec_dtype;
+
+typedef enum {
+    SPEC_WIN_RECT = 0,     /* the reference applies no window (SS:40-68) */
+    SPEC_WIN_HANN = 1      /* periodic Hann, w[n] = 0.5 - 0.5 cos(2 pi n / N) */
+} spec_window;
+
+typedef enum {
+    SPEC_OUT_DB20_F32 = 0, /* float  20 log10(|X| + 1e-10), fftshifted   (SS:76-82 in fp32) */
+    SPEC_OUT_POW_F32 = 1,  /* float  |X|^2, fftshifted */
+    SPEC_OUT_DB20_F64 = 2, /* double 20 log10(|X| + 1e-10): whole pipeline in fp64, as the reference */
+    SPEC_OUT_POW_F64 = 3   /* double |X|^2, fp64 pipeline */
+} spec_out_fmt;
+
+typedef enum {
+    SPEC_PSD_DENSITY = 0,  /* P / (fs * sum w^2)   "Power/Hz" (AnalysisDialogController.java:330) */
+    SPEC_PSD_SPECTRUM = 1  /* P / (sum w)^2 */
+} spec_psd_scaling;
+
+/* spec_create flags */
+#define SPEC_FLAG_REF_CF64_ZERO 0x1u /* reproduce the reference defect: computeMagnitudes has
+                                        no cf64 branch, so cf64 input yields -200 dB (SS:35-63) */
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Bind a context to HIP device `device` (>= 0).  `hip_stream` is a hipStream_t
+ * the caller already owns (e.g. PyTorch's current stream) or NULL to let the
+ * context create its own.  Replaces: the @Service singleton construction of
+ * SpectralService (SS:15-23, one FastFourierTransformer per service). */
+spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx **out);
+void spec_destroy(spec_ctx *ctx);
+
+/* Text of the last failure on `ctx` (or of the last failed spec_create when ctx
+ * is NULL).  Never NULL. */
+const char *spec_last_error(const spec_ctx *ctx);
+const char *spec_status_string(spec_status st);
+
+/* Block until everything queued on the context's stream has finished. */
+spec_status spec_sync(spec_ctx *ctx);
+
+/* The hipStream_t the context launches on (for callers that time with HIP events). */
+void *spec_stream(const spec_ctx *ctx);
+
+/* ---- datatype table ------------------------------------------------------ */
+
+/* SigMF datatype string -> spec_dtype with the reference's startsWith rules
+ * (SS:35-38, ExtractDownConvertService.java:79) and byte-order rule
+ * (SigMfHelper.java:87-91). Unknown strings give SPEC_DT_UNKNOWN. */
+spec_dtype spec_dtype_from_sigmf(const char *datatype);
+
+/* Bytes per interleaved IQ pair: Global.getBytesPerSample() (Global.java:67-79);
+ * SPEC_DT_UNKNOWN -> 8, the reference's fallback. */
+uint32_t spec_bytes_per_sample(spec_dtype dt);
+
+/* Whole lines available in [start_byte, n_bytes): floor((S - nfft)/hop) + 1.
+ * Mirrors the range test of MainController.java:987. */
+uint64_t spec_count_lines(uint64_t n_bytes, uint64_t start_byte, spec_dtype dt,
+                          uint32_t nfft, uint32_t hop);
+
+/* ---- spectrogram --------------------------------------------------------- */
+
+/* Exact replacement for
+ *   double[] SpectralService.computeMagnitudes(MappedByteBuffer buffer,
+ *                                              int startByte, int nfft, String datatype)
+ * (SS:33-85).  `buffer` / `capacity` are the mapped bytes (host memory; the
+ * direct-buffer address on the Java side), `big_endian` is the buffer's
+ * ByteOrder (SigMfHelper.java:87-91).  Writes nfft doubles to `out`
+ * (index 0 = -fs/2).  The whole pipeline runs in fp64 on the GPU.
+ * Errors: non power-of-two nfft -> SPEC_EINVAL; start_byte + nfft*bps >
+ * capacity -> SPEC_ERANGE (the reference's getters would throw). */
+spec_status spec_compute_magnitudes(spec_ctx *ctx, const void *buffer, uint64_t capacity,
+                                    int64_t start_byte, uint32_t nfft, const char *datatype,
+                                    int big_endian, double *out);
+
+/* Batched replacement for the slice loop of MainController.updateDisplay()
+ * (MainController.java:980-999): line t covers samples [t*hop, t*hop + nfft)
+ * counted from start_byte; the reference uses hop == nfft and no window.  A
+ * line whose last byte would pass n_bytes is filled with eof_fill (-150.0 in
+ * the reference, MC:994-998).  `iq` points at byte 0 of the buffer (device
+ * memory when iq_on_device != 0, else host memory that the library stages);
+ * `out` receives n_lines x nfft values of out_fmt, row-major, index 0 = -fs/2.
+ * Device input must be aligned to the component size of dt at iq + start_byte. */
+spec_status spec_waterfall(spec_ctx *ctx, const void *iq, int iq_on_device, uint64_t n_bytes,
+                           uint64_t start_byte, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                           uint64_t n_lines, spec_window window, spec_out_fmt out_fmt,
+                           double eof_fill, void *out, int out_on_device);
+
+/* ---- Welch PSD ----------------------------------------------------------- */
+
+/* Replacement for the call
+ *   PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft)
+ * at AnalysisDialogController.java:308-312 (JDSP v1.3.1; source not in the
+ * reference tree, so window / overlap / scaling are explicit parameters here).
+ * n_psd independent PSDs are computed in one call: PSD b uses n_seg segments
+ * of nfft samples, hop apart, starting at byte start_byte + b*psd_stride_bytes.
+ * freq_out (may be NULL): nfft doubles, (k - nfft/2) fs / nfft, HOST memory.
+ * psd_out: n_psd x nfft floats (fftshifted; 10 log10(P + 1e-20) when db != 0),
+ * device memory when out_on_device != 0. */
+spec_status spec_welch_psd(spec_ctx *ctx, const void *iq, int iq_on_device, uint64_t n_bytes,
+                           uint64_t start_byte, uint64_t psd_stride_bytes, uint32_t n_psd,
+                           spec_dtype dt, uint32_t nfft, uint32_t hop, uint32_t n_seg,
+                           spec_window window, spec_psd_scaling scaling, double fs, int db,
+                           double *freq_out, float *psd_out, int out_on_device);
+
+/* ---- synthetic input (bench / tests) -------------------------- */
+
+/* Fill device memory with the counter-based synthetic IQ recording: samples
+ * [first_sample, first_sample + n_samples) in the byte layout of dt. */
+spec_status spec_synth_iq(spec_ctx *ctx, void *dev_out, spec_dtype dt, uint64_t seed,
+                          uint64_t first_sample, uint64_t n_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECGPU_H */

@@ -1,0 +1,404 @@
+/*
+ * spec_oracle.c -- fp64 CPU restatement of the reference hot path.
+ * TEST INFRASTRUCTURE ONLY; see spec_oracle.h for scope, citations and the
+ * "parity unpinned" statement.  Plain C11, no dependencies beyond libm/pthread.
+ */
+#define _GNU_SOURCE
+#include "spec_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static int starts_with(const char *s, const char *p) {
+    return strncmp(s, p, strlen(p)) == 0;
+}
+
+/* Global.java:67-79 */
+int so_bytes_per_sample(const char *dt) {
+    if (starts_with(dt, "cf32")) return 8;
+    if (starts_with(dt, "ci16")) return 4;
+    if (starts_with(dt, "cu8") || starts_with(dt, "ci8")) return 2;
+    if (starts_with(dt, "cf64")) return 16;
+    return 8; /* Global.java:78 fallback */
+}
+
+/* SigMfHelper.java:87-91: "_le" suffix -> LITTLE_ENDIAN, anything else BIG */
+int so_is_big_endian(const char *dt) {
+    size_t n = strlen(dt);
+    return !(n >= 3 && strcmp(dt + n - 3, "_le") == 0);
+}
+
+/* MappedByteBuffer absolute getters honouring the buffer's byte order */
+static uint16_t get_u16(const uint8_t *p, int be) {
+    return be ? (uint16_t)((p[0] << 8) | p[1]) : (uint16_t)((p[1] << 8) | p[0]);
+}
+static uint32_t get_u32(const uint8_t *p, int be) {
+    return be ? ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]
+              : ((uint32_t)p[3] << 24) | ((uint32_t)p[2] << 16) | ((uint32_t)p[1] << 8) | p[0];
+}
+static uint64_t get_u64(const uint8_t *p, int be) {
+    uint64_t hi = get_u32(be ? p : p + 4, be), lo = get_u32(be ? p + 4 : p, be);
+    return (hi << 32) | lo;
+}
+static double get_f32(const uint8_t *p, int be) {
+    uint32_t u = get_u32(p, be);
+    float f;
+    memcpy(&f, &u, 4);
+    return (double)f;
+}
+static double get_f64(const uint8_t *p, int be) {
+    uint64_t u = get_u64(p, be);
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
+/* the reference resolves the datatype to four booleans once per call
+ * (SS:35-38); same here, as a small enum */
+enum { K_ZERO = 0, K_CI16, K_CF32, K_CU8, K_CI8, K_CF64 };
+static int dtype_kind(const char *dt, int cf64_decode) {
+    if (starts_with(dt, "ci16")) return K_CI16;
+    if (starts_with(dt, "cf32")) return K_CF32;
+    if (starts_with(dt, "cu8")) return K_CU8;
+    if (starts_with(dt, "ci8")) return K_CI8;
+    if (cf64_decode && starts_with(dt, "cf64")) return K_CF64;
+    return K_ZERO; /* SS:60-63 (includes cf64 in the reference's own service) */
+}
+
+/* SpectralService.java:40-65; cf64 per ExtractDownConvertService.java:79-81 */
+static inline void decode_kind(const uint8_t *buf, uint64_t start_byte, uint64_t i,
+                               int kind, int be, double *re, double *im) {
+    const uint8_t *p;
+    switch (kind) {
+    case K_CI16: /* SS:42-45 */
+        p = buf + start_byte + i * 4;
+        *re = (double)(int16_t)get_u16(p, be) / 32768.0;
+        *im = (double)(int16_t)get_u16(p + 2, be) / 32768.0;
+        break;
+    case K_CF32: /* SS:46-49 */
+        p = buf + start_byte + i * 8;
+        *re = get_f32(p, be);
+        *im = get_f32(p + 4, be);
+        break;
+    case K_CU8: /* SS:50-54 */
+        p = buf + start_byte + i * 2;
+        *re = ((double)p[0] - 127.5) / 128;
+        *im = ((double)p[1] - 127.5) / 128;
+        break;
+    case K_CI8: /* SS:55-59 */
+        p = buf + start_byte + i * 2;
+        *re = (double)(int8_t)p[0] / 128;
+        *im = (double)(int8_t)p[1] / 128;
+        break;
+    case K_CF64: /* EDC:79-81 */
+        p = buf + start_byte + i * 16;
+        *re = get_f64(p, be);
+        *im = get_f64(p + 8, be);
+        break;
+    default: /* SS:60-63 */
+        *re = 0.0;
+        *im = 0.0;
+    }
+}
+
+void so_decode_sample(const uint8_t *buf, uint64_t start_byte, uint64_t i,
+                      const char *dt, int cf64_decode, double *re, double *im) {
+    decode_kind(buf, start_byte, i, dtype_kind(dt, cf64_decode), so_is_big_endian(dt), re, im);
+}
+
+/* commons-math3 3.6.1 FastFourierTransformer.transformInPlace, STANDARD,
+ * FORWARD, restated: bit-reversal shuffle, then log2(n) radix-2 stages with
+ * w = exp(-2 pi i j / len).  Twiddles are evaluated in long double and rounded
+ * to double once (the library uses precomputed double tables). */
+static int make_twiddles(uint32_t n, double **wr_out, double **wi_out) {
+    double *wr = (double *)malloc(sizeof(double) * (n / 2 + 1));
+    double *wi = (double *)malloc(sizeof(double) * (n / 2 + 1));
+    if (!wr || !wi) { free(wr); free(wi); return -1; }
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (uint32_t j = 0; j < n / 2; j++) {
+        long double a = -two_pi * (long double)j / (long double)n;
+        wr[j] = (double)cosl(a);
+        wi[j] = (double)sinl(a);
+    }
+    *wr_out = wr;
+    *wi_out = wi;
+    return 0;
+}
+
+static void fft_forward_tw(double *re, double *im, uint32_t n,
+                           const double *wr, const double *wi) {
+    for (uint32_t i = 1, j = 0; i < n; i++) {
+        uint32_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (uint32_t len = 2; len <= n; len <<= 1) {
+        uint32_t half = len >> 1, step = n / len;
+        for (uint32_t base = 0; base < n; base += len) {
+            for (uint32_t j = 0; j < half; j++) {
+                double cr = wr[j * step], ci = wi[j * step];
+                uint32_t a = base + j, b = a + half;
+                double tr = re[b] * cr - im[b] * ci;
+                double ti = re[b] * ci + im[b] * cr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr;        im[a] += ti;
+            }
+        }
+    }
+}
+
+int so_fft_forward(double *re, double *im, uint32_t n) {
+    if (n == 0 || (n & (n - 1)) != 0) return -1;
+    if (n == 1) return 0;
+    double *wr, *wi;
+    if (make_twiddles(n, &wr, &wi)) return -1;
+    fft_forward_tw(re, im, n, wr, wi);
+    free(wr);
+    free(wi);
+    return 0;
+}
+
+static void make_window(double *w, uint32_t n, int window) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (uint32_t i = 0; i < n; i++)
+        w[i] = (window == SO_WIN_HANN)
+                   ? (double)(0.5L - 0.5L * cosl(two_pi * (long double)i / (long double)n))
+                   : 1.0;
+}
+
+/* one line: decode (SS:40-65) -> optional window -> FFT (SS:68); leaves the
+ * unshifted spectrum in re/im */
+static void line_spectrum(const uint8_t *buf, uint64_t start_byte, uint32_t nfft,
+                          const char *dt, int cf64_decode, const double *win,
+                          const double *wr, const double *wi,
+                          double *re, double *im) {
+    int kind = dtype_kind(dt, cf64_decode), be = so_is_big_endian(dt);
+    for (uint32_t i = 0; i < nfft; i++) {
+        decode_kind(buf, start_byte, i, kind, be, &re[i], &im[i]);
+        if (win) { re[i] *= win[i]; im[i] *= win[i]; }
+    }
+    if (nfft > 1) fft_forward_tw(re, im, nfft, wr, wi);
+}
+
+/* SpectralService.java:33-85 */
+int so_compute_magnitudes(const uint8_t *buf, uint64_t start_byte, uint32_t nfft,
+                          const char *dt, int cf64_decode, double *out) {
+    if (nfft == 0 || (nfft & (nfft - 1)) != 0) return -1;
+    double *re = (double *)malloc(sizeof(double) * nfft * 2), *wr, *wi;
+    if (!re) return -1;
+    if (make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
+    double *im = re + nfft;
+    line_spectrum(buf, start_byte, nfft, dt, cf64_decode, NULL, wr, wi, re, im);
+    uint32_t half = nfft / 2;
+    for (uint32_t i = 0; i < nfft; i++) {
+        uint32_t s = (i + half) % nfft;            /* SS:78 */
+        double a = hypot(re[i], im[i]);            /* Complex.abs(), SS:80 */
+        out[s] = 20 * log10(a + 1e-10);            /* SS:81 */
+    }
+    free(re); free(wr); free(wi);
+    return 0;
+}
+
+uint64_t so_count_lines(uint64_t capacity, uint64_t start_byte, const char *dt,
+                        uint32_t nfft, uint32_t hop) {
+    uint64_t bps = (uint64_t)so_bytes_per_sample(dt);
+    if (start_byte >= capacity || hop == 0) return 0;
+    uint64_t s = (capacity - start_byte) / bps;
+    if (s < nfft) return 0;
+    return (s - nfft) / hop + 1;
+}
+
+/* MainController.java:980-999 (hop generalised; reference hop == nfft).
+ * out_stride is the distance in doubles between consecutive output lines
+ * (nfft for the public entry; 0 lets the timing driver reuse one line). */
+static int waterfall_impl(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
+                          const char *dt, int cf64_decode, uint32_t nfft, uint32_t hop,
+                          uint64_t n_lines, int window, double eof_fill, int power_out,
+                          double *out, uint64_t out_stride, double *checksum) {
+    if (nfft == 0 || (nfft & (nfft - 1)) != 0 || hop == 0) return -1;
+    uint64_t bps = (uint64_t)so_bytes_per_sample(dt);
+    double *re = (double *)malloc(sizeof(double) * nfft * 3), *wr, *wi;
+    if (!re) return -1;
+    if (make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
+    double *im = re + nfft, *win = im + nfft;
+    make_window(win, nfft, window);
+    uint32_t half = nfft / 2;
+    double cs = 0;
+    for (uint64_t t = 0; t < n_lines; t++) {
+        uint64_t byte_off = start_byte + t * (uint64_t)hop * bps;   /* MC:984-985 */
+        double *o = out + t * out_stride;
+        if (byte_off + (uint64_t)nfft * bps <= capacity) {           /* MC:987 */
+            line_spectrum(buf, byte_off, nfft, dt, cf64_decode,
+                          window == SO_WIN_RECT ? NULL : win, wr, wi, re, im);
+            for (uint32_t i = 0; i < nfft; i++) {
+                uint32_t s = (i + half) % nfft;                      /* SS:78 */
+                if (power_out) o[s] = re[i] * re[i] + im[i] * im[i];
+                else o[s] = 20 * log10(hypot(re[i], im[i]) + 1e-10); /* SS:80-81 */
+            }
+        } else {
+            for (uint32_t i = 0; i < nfft; i++) o[i] = eof_fill;    /* MC:994-998 */
+        }
+        cs += o[(t * 2654435761u) % nfft];
+    }
+    if (checksum) *checksum = cs;
+    free(re); free(wr); free(wi);
+    return 0;
+}
+
+int so_waterfall(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
+                 const char *dt, int cf64_decode, uint32_t nfft, uint32_t hop,
+                 uint64_t n_lines, int window, double eof_fill, int power_out,
+                 double *out) {
+    return waterfall_impl(buf, capacity, start_byte, dt, cf64_decode, nfft, hop,
+                          n_lines, window, eof_fill, power_out, out, nfft, NULL);
+}
+
+int so_welch_psd(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
+                 const char *dt, int cf64_decode, uint32_t nfft, uint32_t hop,
+                 uint32_t n_seg, int window, int scaling, double fs, int psd_db,
+                 double *freq_out, double *psd_out) {
+    if (nfft == 0 || (nfft & (nfft - 1)) != 0 || hop == 0 || n_seg == 0) return -1;
+    uint64_t bps = (uint64_t)so_bytes_per_sample(dt);
+    if (start_byte + ((uint64_t)(n_seg - 1) * hop + nfft) * bps > capacity) return -1;
+    double *re = (double *)malloc(sizeof(double) * nfft * 4), *wr, *wi;
+    if (!re) return -1;
+    if (make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
+    double *im = re + nfft, *win = im + nfft, *acc = win + nfft;
+    make_window(win, nfft, window);
+    double s1 = 0, s2 = 0;
+    for (uint32_t i = 0; i < nfft; i++) { s1 += win[i]; s2 += win[i] * win[i]; acc[i] = 0; }
+    for (uint32_t s = 0; s < n_seg; s++) {
+        line_spectrum(buf, start_byte + (uint64_t)s * hop * bps, nfft, dt,
+                      cf64_decode, win, wr, wi, re, im);
+        for (uint32_t i = 0; i < nfft; i++) acc[i] += re[i] * re[i] + im[i] * im[i];
+    }
+    double norm = (scaling == SO_PSD_DENSITY) ? 1.0 / (fs * s2) : 1.0 / (s1 * s1);
+    norm /= (double)n_seg;
+    uint32_t half = nfft / 2;
+    for (uint32_t i = 0; i < nfft; i++) {
+        uint32_t sidx = (i + half) % nfft;
+        double p = acc[i] * norm;
+        psd_out[sidx] = psd_db ? 10 * log10(p + 1e-20) : p;
+    }
+    for (uint32_t k = 0; k < nfft; k++)
+        freq_out[k] = ((double)k - (double)half) * fs / (double)nfft;
+    free(re); free(wr); free(wi);
+    return 0;
+}
+
+/* MainController.java:1273-1274 */
+double so_display_conversion(double fs, uint32_t nfft) {
+    return 10 * log10(fs / nfft) + 20 * log10((double)nfft);
+}
+
+/* ---------------- synthetic IQ ---------------- */
+static uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+/* tone frequencies as exact 32-bit phase increments: 0.123 and -0.31 cycles/sample */
+#define SO_TONE1_INC 528280977u  /* round(0.123 * 2^32) */
+#define SO_TONE2_INC 2963527434u /* round((1-0.31) * 2^32) */
+
+static void synth_sample(uint64_t seed, uint64_t n, double *re, double *im) {
+    const double two_pi = 6.283185307179586476925286766559;
+    uint64_t a = splitmix64(seed ^ (2 * n)), b = splitmix64(seed ^ (2 * n + 1));
+    double u1 = ((double)(a >> 40) + 0.5) * (1.0 / 16777216.0);
+    double u2 = ((double)(b >> 40) + 0.5) * (1.0 / 16777216.0);
+    double r = 0.05 * sqrt(-2.0 * log(u1));
+    uint32_t p1 = (uint32_t)(n * (uint64_t)SO_TONE1_INC);
+    uint32_t p2 = (uint32_t)(n * (uint64_t)SO_TONE2_INC);
+    double a1 = two_pi * (double)p1 * (1.0 / 4294967296.0);
+    double a2 = two_pi * (double)p2 * (1.0 / 4294967296.0);
+    *re = r * cos(two_pi * u2) + 0.5 * cos(a1) + 0.1 * cos(a2);
+    *im = r * sin(two_pi * u2) + 0.5 * sin(a1) + 0.1 * sin(a2);
+}
+static double clip1(double x) { return x < -1.0 ? -1.0 : (x > 1.0 ? 1.0 : x); }
+static void put_u16(uint8_t *p, uint16_t v, int be) {
+    if (be) { p[0] = (uint8_t)(v >> 8); p[1] = (uint8_t)v; }
+    else { p[1] = (uint8_t)(v >> 8); p[0] = (uint8_t)v; }
+}
+static void put_u32(uint8_t *p, uint32_t v, int be) {
+    for (int k = 0; k < 4; k++) p[be ? 3 - k : k] = (uint8_t)(v >> (8 * k));
+}
+static void put_u64(uint8_t *p, uint64_t v, int be) {
+    for (int k = 0; k < 8; k++) p[be ? 7 - k : k] = (uint8_t)(v >> (8 * k));
+}
+
+int so_synth_iq(uint8_t *out, const char *dt, uint64_t seed,
+                uint64_t first_sample, uint64_t n_samples) {
+    int be = so_is_big_endian(dt);
+    for (uint64_t i = 0; i < n_samples; i++) {
+        double v[2];
+        synth_sample(seed, first_sample + i, &v[0], &v[1]);
+        for (int c = 0; c < 2; c++) {
+            if (starts_with(dt, "cf32")) {
+                float f = (float)v[c]; uint32_t u; memcpy(&u, &f, 4);
+                put_u32(out + i * 8 + c * 4, u, be);
+            } else if (starts_with(dt, "cf64")) {
+                uint64_t u; memcpy(&u, &v[c], 8);
+                put_u64(out + i * 16 + c * 8, u, be);
+            } else if (starts_with(dt, "ci16")) {
+                int16_t q = (int16_t)lrint(32767.0 * clip1(v[c]));
+                put_u16(out + i * 4 + c * 2, (uint16_t)q, be);
+            } else if (starts_with(dt, "ci8")) {
+                out[i * 2 + c] = (uint8_t)(int8_t)lrint(127.0 * clip1(v[c]));
+            } else if (starts_with(dt, "cu8")) {
+                out[i * 2 + c] = (uint8_t)lrint(127.5 + 127.0 * clip1(v[c]));
+            } else {
+                return -1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ---------------- timed driver for the CPU baseline ---------------- */
+typedef struct {
+    const uint8_t *buf; uint64_t capacity; const char *dt;
+    uint32_t nfft, hop; uint64_t l0, l1; int window; double checksum;
+} job_t;
+
+static void *job_main(void *p) {
+    job_t *j = (job_t *)p;
+    uint64_t bps = (uint64_t)so_bytes_per_sample(j->dt);
+    double *line = (double *)malloc(sizeof(double) * j->nfft);
+    /* tables are built once per thread, as the reference builds its
+     * FastFourierTransformer once (SpectralService.java:23) */
+    waterfall_impl(j->buf, j->capacity, j->l0 * (uint64_t)j->hop * bps, j->dt, 1,
+                   j->nfft, j->hop, j->l1 - j->l0, j->window, -150.0, 0, line, 0,
+                   &j->checksum);
+    free(line);
+    return NULL;
+}
+
+double so_time_waterfall(const uint8_t *buf, uint64_t capacity, const char *dt,
+                         uint32_t nfft, uint32_t hop, uint64_t n_lines, int window,
+                         int threads, double *out_checksum) {
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    job_t jobs[256];
+    pthread_t th[256];
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < threads; i++) {
+        jobs[i] = (job_t){buf, capacity, dt, nfft, hop,
+                          n_lines * (uint64_t)i / threads,
+                          n_lines * (uint64_t)(i + 1) / threads, window, 0.0};
+        pthread_create(&th[i], NULL, job_main, &jobs[i]);
+    }
+    double cs = 0;
+    for (int i = 0; i < threads; i++) { pthread_join(th[i], NULL); cs += jobs[i].checksum; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (out_checksum) *out_checksum = cs;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,207 @@
+"""Python face of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Two independent restatements of the reference hot path live here:
+
+* ``C``   -- ctypes bindings to ``oracle/libspec_oracle.so`` (spec_oracle.c), the
+  fp64 radix-2 restatement of ``SpectralService.computeMagnitudes``
+  (services/SpectralService.java:33-85) and of the ``MainController.updateDisplay``
+  line loop (controllers/MainController.java:980-999).
+* ``np_*`` -- a numpy restatement that uses ``numpy.fft.fft`` (a different FFT
+  implementation) so the two can be checked against each other.
+
+Parity status: "parity unpinned" against an execution of the Java reference (no
+JVM / jars available); pinned against analytic known-answer tests and the
+numpy / scipy cross-checks in tests/test_oracle.py.
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may
+import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libspec_oracle.so")
+
+WIN_RECT, WIN_HANN = 0, 1
+PSD_DENSITY, PSD_SPECTRUM = 0, 1
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle with gcc (a few hundred ms)."""
+    src = os.path.join(_HERE, "spec_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        u8p, dp = C.c_void_p, C.c_void_p
+        L.so_bytes_per_sample.argtypes = [C.c_char_p]
+        L.so_is_big_endian.argtypes = [C.c_char_p]
+        L.so_fft_forward.argtypes = [dp, dp, C.c_uint32]
+        L.so_compute_magnitudes.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_int, dp]
+        L.so_waterfall.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_uint32,
+                                   C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_int, dp]
+        L.so_count_lines.argtypes = [C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint32, C.c_uint32]
+        L.so_count_lines.restype = C.c_uint64
+        L.so_welch_psd.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_uint32,
+                                   C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_double, C.c_int,
+                                   dp, dp]
+        L.so_display_conversion.argtypes = [C.c_double, C.c_uint32]
+        L.so_display_conversion.restype = C.c_double
+        L.so_synth_iq.argtypes = [u8p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.so_time_waterfall.argtypes = [u8p, C.c_uint64, C.c_char_p, C.c_uint32, C.c_uint32,
+                                        C.c_uint64, C.c_int, C.c_int, dp]
+        L.so_time_waterfall.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _bytes_view(buf) -> np.ndarray:
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8).reshape(-1)
+    return np.ascontiguousarray(a)
+
+
+def bytes_per_sample(datatype: str) -> int:
+    return lib().so_bytes_per_sample(datatype.encode())
+
+
+def is_big_endian(datatype: str) -> bool:
+    return bool(lib().so_is_big_endian(datatype.encode()))
+
+
+def fft_forward(x: np.ndarray) -> np.ndarray:
+    re = np.ascontiguousarray(x.real, dtype=np.float64).copy()
+    im = np.ascontiguousarray(x.imag, dtype=np.float64).copy()
+    rc = lib().so_fft_forward(re.ctypes.data, im.ctypes.data, len(re))
+    if rc:
+        raise ValueError("nfft must be a power of two")
+    return re + 1j * im
+
+
+def compute_magnitudes(buf, start_byte: int, nfft: int, datatype: str, cf64_decode: bool = False) -> np.ndarray:
+    """SpectralService.computeMagnitudes (SS:33-85); returns double[nfft]."""
+    b = _bytes_view(buf)
+    need = start_byte + nfft * bytes_per_sample(datatype)
+    if start_byte < 0 or need > b.size:
+        raise IndexError("IndexOutOfBoundsException: %d > %d" % (need, b.size))
+    out = np.empty(nfft, dtype=np.float64)
+    rc = lib().so_compute_magnitudes(b.ctypes.data, start_byte, nfft, datatype.encode(),
+                                     int(cf64_decode), out.ctypes.data)
+    if rc:
+        raise ValueError("nfft must be a power of two")
+    return out
+
+
+def count_lines(capacity: int, start_byte: int, datatype: str, nfft: int, hop: int) -> int:
+    return int(lib().so_count_lines(capacity, start_byte, datatype.encode(), nfft, hop))
+
+
+def waterfall(buf, start_byte: int, datatype: str, nfft: int, hop: int, n_lines: int,
+              window: int = WIN_RECT, eof_fill: float = -150.0, power: bool = False,
+              cf64_decode: bool = True) -> np.ndarray:
+    b = _bytes_view(buf)
+    out = np.empty((n_lines, nfft), dtype=np.float64)
+    rc = lib().so_waterfall(b.ctypes.data, b.size, start_byte, datatype.encode(), int(cf64_decode),
+                            nfft, hop, n_lines, window, eof_fill, int(power), out.ctypes.data)
+    if rc:
+        raise ValueError("bad nfft/hop")
+    return out
+
+
+def welch_psd(buf, start_byte: int, datatype: str, nfft: int, hop: int, n_seg: int,
+              window: int = WIN_HANN, scaling: int = PSD_DENSITY, fs: float = 1.0,
+              db: bool = False, cf64_decode: bool = True):
+    b = _bytes_view(buf)
+    f = np.empty(nfft, dtype=np.float64)
+    p = np.empty(nfft, dtype=np.float64)
+    rc = lib().so_welch_psd(b.ctypes.data, b.size, start_byte, datatype.encode(), int(cf64_decode),
+                            nfft, hop, n_seg, window, scaling, fs, int(db), f.ctypes.data, p.ctypes.data)
+    if rc:
+        raise ValueError("bad welch arguments")
+    return f, p
+
+
+def display_conversion(fs: float, nfft: int) -> float:
+    return float(lib().so_display_conversion(fs, nfft))
+
+
+def synth_iq(datatype: str, seed: int, first_sample: int, n_samples: int) -> np.ndarray:
+    """SURVEY 8(d) counter-based synthetic IQ, as raw file bytes (uint8)."""
+    out = np.empty(n_samples * bytes_per_sample(datatype), dtype=np.uint8)
+    rc = lib().so_synth_iq(out.ctypes.data, datatype.encode(), seed, first_sample, n_samples)
+    if rc:
+        raise ValueError("unsupported datatype " + datatype)
+    return out
+
+
+def time_waterfall(buf, datatype: str, nfft: int, hop: int, n_lines: int, window: int, threads: int):
+    b = _bytes_view(buf)
+    cs = C.c_double(0)
+    t = lib().so_time_waterfall(b.ctypes.data, b.size, datatype.encode(), nfft, hop, n_lines,
+                                window, threads, C.addressof(cs))
+    return float(t), float(cs.value)
+
+
+# --------------------------------------------------------------------------
+# numpy restatement (independent FFT implementation)
+# --------------------------------------------------------------------------
+def np_decode(buf, start_byte: int, n: int, datatype: str, cf64_decode: bool = True) -> np.ndarray:
+    """SS:40-65 decode table (+cf64 per EDC:79-81) -> complex128[n]."""
+    b = _bytes_view(buf)
+    bo = ">" if is_big_endian(datatype) else "<"
+    if datatype.startswith("ci16"):
+        v = np.frombuffer(b, dtype=bo + "i2", count=2 * n, offset=start_byte).astype(np.float64) / 32768.0
+    elif datatype.startswith("cf32"):
+        v = np.frombuffer(b, dtype=bo + "f4", count=2 * n, offset=start_byte).astype(np.float64)
+    elif datatype.startswith("cu8"):
+        v = (np.frombuffer(b, dtype=np.uint8, count=2 * n, offset=start_byte).astype(np.float64) - 127.5) / 128
+    elif datatype.startswith("ci8"):
+        v = np.frombuffer(b, dtype=np.int8, count=2 * n, offset=start_byte).astype(np.float64) / 128
+    elif datatype.startswith("cf64") and cf64_decode:
+        v = np.frombuffer(b, dtype=bo + "f8", count=2 * n, offset=start_byte).astype(np.float64)
+    else:
+        v = np.zeros(2 * n)
+    return v[0::2] + 1j * v[1::2]
+
+
+def np_window(nfft: int, window: int) -> np.ndarray:
+    if window == WIN_HANN:
+        return 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(nfft) / nfft)
+    return np.ones(nfft)
+
+
+def np_spectrum(buf, start_byte: int, datatype: str, nfft: int, hop: int, n_lines: int,
+                window: int = WIN_RECT) -> np.ndarray:
+    """Unshifted complex spectra [n_lines, nfft] (all lines must be in range)."""
+    bps = bytes_per_sample(datatype)
+    w = np_window(nfft, window)
+    rows = [np_decode(buf, start_byte + t * hop * bps, nfft, datatype) * w for t in range(n_lines)]
+    return np.fft.fft(np.asarray(rows), axis=1)
+
+
+def np_waterfall(buf, start_byte: int, datatype: str, nfft: int, hop: int, n_lines: int,
+                 window: int = WIN_RECT, eof_fill: float = -150.0) -> np.ndarray:
+    b = _bytes_view(buf)
+    bps = bytes_per_sample(datatype)
+    out = np.full((n_lines, nfft), eof_fill, dtype=np.float64)
+    w = np_window(nfft, window)
+    for t in range(n_lines):
+        off = start_byte + t * hop * bps
+        if off + nfft * bps <= b.size:
+            X = np.fft.fft(np_decode(b, off, nfft, datatype) * w)
+            out[t] = np.fft.fftshift(20 * np.log10(np.abs(X) + 1e-10))
+    return out

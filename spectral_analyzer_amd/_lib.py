@@ -1,0 +1,64 @@
+"""ctypes binding of the C ABI in include/specgpu.h (libspecgpu.so).
+
+The library is the product; this module only loads it.  There is no Python or
+CPU fallback: if the shared object is missing or fails to load, importing
+callers get an ImportError telling them to run ``python -m
+spectral_analyzer_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspecgpu.so")
+
+# spec_status
+SPEC_OK, SPEC_EINVAL, SPEC_ERANGE, SPEC_EDEVICE, SPEC_ENOMEM, SPEC_EUNSUPPORTED = range(6)
+# spec_dtype
+(DT_UNKNOWN, DT_CU8, DT_CI8, DT_CI16_LE, DT_CI16_BE, DT_CF32_LE, DT_CF32_BE, DT_CF64_LE,
+ DT_CF64_BE) = range(9)
+WIN_RECT, WIN_HANN = 0, 1
+OUT_DB20_F32, OUT_POW_F32, OUT_DB20_F64, OUT_POW_F64 = range(4)
+PSD_DENSITY, PSD_SPECTRUM = 0, 1
+FLAG_REF_CF64_ZERO = 0x1
+
+# every symbol include/specgpu.h declares, with its ctypes signature
+_u64, _u32, _i32, _vp, _cp, _dbl = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_char_p, C.c_double
+SIGNATURES = {
+    "spec_create": (_i32, [_i32, _vp, _u32, C.POINTER(_vp)]),
+    "spec_destroy": (None, [_vp]),
+    "spec_last_error": (_cp, [_vp]),
+    "spec_status_string": (_cp, [_i32]),
+    "spec_sync": (_i32, [_vp]),
+    "spec_stream": (_vp, [_vp]),
+    "spec_dtype_from_sigmf": (_i32, [_cp]),
+    "spec_bytes_per_sample": (_u32, [_i32]),
+    "spec_count_lines": (_u64, [_u64, _u64, _i32, _u32, _u32]),
+    "spec_compute_magnitudes": (_i32, [_vp, _vp, _u64, C.c_int64, _u32, _cp, _i32, _vp]),
+    "spec_waterfall": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u64, _i32, _i32, _dbl, _vp, _i32]),
+    "spec_welch_psd": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _u32, _i32, _u32, _u32, _u32, _i32, _i32,
+                              _dbl, _i32, _vp, _vp, _i32]),
+    "spec_synth_iq": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libspecgpu.so; raises ImportError (never falls back) when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libspecgpu.so is not built (%s). Run `python -m spectral_analyzer_amd.build`; "
+                "there is no CPU fallback." % LIB_PATH)
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # missing ROCm runtime etc.
+            raise ImportError("cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib

@@ -1,0 +1,66 @@
+"""Build libspecgpu.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+    python -m spectral_analyzer_amd.build [--force]
+
+The library is built in-tree (spectral_analyzer_amd/lib/libspecgpu.so) so that
+it travels with the repository snapshot; hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libspecgpu.so")
+SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_misc.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+         "-ffp-contract=fast"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def _newest_dep() -> float:
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(HERE, "..", "include", "specgpu.h"))
+    return max(os.path.getmtime(d) for d in deps)
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_dep():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

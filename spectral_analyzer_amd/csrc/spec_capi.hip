@@ -1,0 +1,518 @@
+// spec_capi.hip -- implementation of the C ABI declared in include/specgpu.h.
+// Host code only: argument checking (the reference's error behaviour), plan /
+// table cache, host<->device staging, launch sequencing.  No CPU compute path.
+#include "../../include/specgpu.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "spec_fft.h"
+#include "spec_internal.h"
+
+using namespace specgpu;
+
+struct spec_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t flags = 0;
+    std::string err;
+    // tables keyed by (log2n << 1 | f64) and (log2n << 4 | window << 1 | f64)
+    std::map<uint32_t, void *> twiddles;
+    std::map<uint32_t, void *> windows;
+    std::map<uint32_t, std::pair<double, double>> window_sums;  // sum w, sum w^2
+    // grow-only device scratch
+    void *stage_in = nullptr;  size_t stage_in_bytes = 0;
+    void *stage_out = nullptr; size_t stage_out_bytes = 0;
+    void *scratch = nullptr;   size_t scratch_bytes = 0;
+};
+
+static thread_local std::string g_create_err;
+
+static spec_status fail(spec_ctx *c, spec_status st, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return st;
+}
+
+#define HIP_TRY(c, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(c, e__ == hipErrorOutOfMemory ? SPEC_ENOMEM : SPEC_EDEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e__));                                             \
+    } while (0)
+
+static int kind_of(spec_dtype dt, uint32_t flags) {
+    switch (dt) {
+    case SPEC_DT_CU8: return K_CU8;
+    case SPEC_DT_CI8: return K_CI8;
+    case SPEC_DT_CI16_LE: case SPEC_DT_CI16_BE: return K_CI16;
+    case SPEC_DT_CF32_LE: case SPEC_DT_CF32_BE: return K_CF32;
+    case SPEC_DT_CF64_LE: case SPEC_DT_CF64_BE: return (flags & SPEC_FLAG_REF_CF64_ZERO) ? K_ZERO : K_CF64;
+    default: return K_ZERO;
+    }
+}
+static int is_be(spec_dtype dt) { return dt == SPEC_DT_CI16_BE || dt == SPEC_DT_CF32_BE || dt == SPEC_DT_CF64_BE; }
+static uint32_t component_bytes(spec_dtype dt) {
+    switch (dt) {
+    case SPEC_DT_CU8: case SPEC_DT_CI8: return 1;
+    case SPEC_DT_CI16_LE: case SPEC_DT_CI16_BE: return 2;
+    case SPEC_DT_CF64_LE: case SPEC_DT_CF64_BE: return 8;
+    default: return 4;
+    }
+}
+static bool dtype_valid(int dt) { return dt >= SPEC_DT_UNKNOWN && dt <= SPEC_DT_CF64_BE; }
+static int ilog2(uint32_t n) { int l = 0; while ((1u << l) < n) ++l; return l; }
+
+extern "C" {
+
+const char *spec_status_string(spec_status st) {
+    switch (st) {
+    case SPEC_OK: return "SPEC_OK";
+    case SPEC_EINVAL: return "SPEC_EINVAL";
+    case SPEC_ERANGE: return "SPEC_ERANGE";
+    case SPEC_EDEVICE: return "SPEC_EDEVICE";
+    case SPEC_ENOMEM: return "SPEC_ENOMEM";
+    case SPEC_EUNSUPPORTED: return "SPEC_EUNSUPPORTED";
+    default: return "SPEC_?";
+    }
+}
+
+const char *spec_last_error(const spec_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+spec_dtype spec_dtype_from_sigmf(const char *s) {
+    if (!s) return SPEC_DT_UNKNOWN;
+    const size_t n = strlen(s);
+    const bool le = n >= 3 && strcmp(s + n - 3, "_le") == 0;  // SigMfHelper.java:87-91
+    auto sw = [&](const char *p) { return strncmp(s, p, strlen(p)) == 0; };
+    if (sw("ci16")) return le ? SPEC_DT_CI16_LE : SPEC_DT_CI16_BE;  // SS:35
+    if (sw("cf32")) return le ? SPEC_DT_CF32_LE : SPEC_DT_CF32_BE;  // SS:36
+    if (sw("cu8")) return SPEC_DT_CU8;                              // SS:37
+    if (sw("ci8")) return SPEC_DT_CI8;                              // SS:38
+    if (sw("cf64")) return le ? SPEC_DT_CF64_LE : SPEC_DT_CF64_BE;  // EDC:79
+    return SPEC_DT_UNKNOWN;
+}
+
+uint32_t spec_bytes_per_sample(spec_dtype dt) {  // Global.java:67-79
+    switch (dt) {
+    case SPEC_DT_CU8: case SPEC_DT_CI8: return 2;
+    case SPEC_DT_CI16_LE: case SPEC_DT_CI16_BE: return 4;
+    case SPEC_DT_CF64_LE: case SPEC_DT_CF64_BE: return 16;
+    default: return 8;
+    }
+}
+
+uint64_t spec_count_lines(uint64_t n_bytes, uint64_t start_byte, spec_dtype dt, uint32_t nfft, uint32_t hop) {
+    if (hop == 0 || nfft == 0 || start_byte >= n_bytes) return 0;
+    const uint64_t s = (n_bytes - start_byte) / spec_bytes_per_sample(dt);
+    return s < nfft ? 0 : (s - nfft) / hop + 1;
+}
+
+spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx **out) {
+    if (!out) return fail(nullptr, SPEC_EINVAL, "spec_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+        return fail(nullptr, SPEC_EDEVICE, "spec_create: no HIP device (%s); there is no CPU backend",
+                    e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+    if (device < 0 || device >= n_dev) return fail(nullptr, SPEC_EINVAL, "spec_create: device %d of %d", device, n_dev);
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, SPEC_EDEVICE, "spec_create: device %d is %s; this library carries gfx950 code only", device,
+                    prop.gcnArchName);
+    spec_ctx *c = new (std::nothrow) spec_ctx;
+    if (!c) return fail(nullptr, SPEC_ENOMEM, "spec_create: out of host memory");
+    c->device = device;
+    c->flags = flags;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, SPEC_EDEVICE, "hipSetDevice(%d) failed", device); }
+    if (hip_stream) {
+        c->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return fail(nullptr, SPEC_EDEVICE, "hipStreamCreate failed");
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return SPEC_OK;
+}
+
+void spec_destroy(spec_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->twiddles) (void)hipFree(kv.second);
+    for (auto &kv : c->windows) (void)hipFree(kv.second);
+    (void)hipFree(c->stage_in);
+    (void)hipFree(c->stage_out);
+    (void)hipFree(c->scratch);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+spec_status spec_sync(spec_ctx *c) {
+    if (!c) return SPEC_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPEC_OK;
+}
+
+void *spec_stream(const spec_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------
+// W_N^m = exp(-2 pi i m / N), evaluated in long double, rounded once.
+static spec_status get_twiddles(spec_ctx *c, int log2n, bool f64, const void **out) {
+    const uint32_t key = ((uint32_t)log2n << 1) | (f64 ? 1u : 0u);
+    auto it = c->twiddles.find(key);
+    if (it != c->twiddles.end()) { *out = it->second; return SPEC_OK; }
+    const size_t n = (size_t)1 << log2n, esz = f64 ? 16 : 8;
+    std::vector<unsigned char> host(n * esz);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (size_t m = 0; m < n; ++m) {
+        // exact at the eight octant points, symmetric elsewhere
+        const long double a = -two_pi * (long double)m / (long double)n;
+        const long double cr = cosl(a), ci = sinl(a);
+        if (f64) { double *p = reinterpret_cast<double *>(host.data()) + 2 * m; p[0] = (double)cr; p[1] = (double)ci; }
+        else { float *p = reinterpret_cast<float *>(host.data()) + 2 * m; p[0] = (float)cr; p[1] = (float)ci; }
+    }
+    void *dev = nullptr;
+    HIP_TRY(c, hipMalloc(&dev, n * esz));
+    hipError_t e = hipMemcpyAsync(dev, host.data(), n * esz, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host vector dies at return
+    if (e != hipSuccess) { (void)hipFree(dev); return fail(c, SPEC_EDEVICE, "twiddle upload: %s", hipGetErrorString(e)); }
+    c->twiddles[key] = dev;
+    *out = dev;
+    return SPEC_OK;
+}
+
+static spec_status get_window(spec_ctx *c, int log2n, bool f64, spec_window w, const void **out, double *s1,
+                              double *s2) {
+    const size_t n = (size_t)1 << log2n;
+    if (w == SPEC_WIN_RECT) {
+        *out = nullptr;
+        if (s1) *s1 = (double)n;
+        if (s2) *s2 = (double)n;
+        return SPEC_OK;
+    }
+    const uint32_t key = ((uint32_t)log2n << 4) | ((uint32_t)w << 1) | (f64 ? 1u : 0u);
+    auto it = c->windows.find(key);
+    if (it == c->windows.end()) {
+        const size_t esz = f64 ? 8 : 4;
+        std::vector<unsigned char> host(n * esz);
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        double a1 = 0, a2 = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const double v = (double)(0.5L - 0.5L * cosl(two_pi * (long double)i / (long double)n));
+            a1 += v; a2 += v * v;
+            if (f64) reinterpret_cast<double *>(host.data())[i] = v;
+            else reinterpret_cast<float *>(host.data())[i] = (float)v;
+        }
+        void *dev = nullptr;
+        HIP_TRY(c, hipMalloc(&dev, n * esz));
+        hipError_t e = hipMemcpyAsync(dev, host.data(), n * esz, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(dev); return fail(c, SPEC_EDEVICE, "window upload: %s", hipGetErrorString(e)); }
+        c->windows[key] = dev;
+        c->window_sums[key] = {a1, a2};
+        it = c->windows.find(key);
+    }
+    *out = it->second;
+    if (s1) *s1 = c->window_sums[key].first;
+    if (s2) *s2 = c->window_sums[key].second;
+    return SPEC_OK;
+}
+
+static spec_status grow(spec_ctx *c, void **buf, size_t *have, size_t need) {
+    if (*have >= need) return SPEC_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *have = 0; }
+    HIP_TRY(c, hipMalloc(buf, need));
+    *have = need;
+    return SPEC_OK;
+}
+
+// choose how many consecutive lines one workgroup walks
+static uint32_t pick_lines_per_wg(uint64_t n_lines, int lpw) {
+    const uint64_t target_wgs = 256ull * 48;  // ~10 rounds of resident workgroups: small tail, some L2 reuse
+    uint64_t per = (n_lines + target_wgs - 1) / target_wgs;
+    per = (per + lpw - 1) / lpw * lpw;
+    if (per < (uint64_t)lpw) per = lpw;
+    const uint64_t cap = 32ull * lpw;
+    if (per > cap) per = cap;
+    return (uint32_t)per;
+}
+
+// launch the spectrogram kernel(s) for lines that lie fully inside the buffer
+static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt, int log2n, uint32_t hop,
+                             uint64_t n_lines, spec_window window, spec_out_fmt fmt, void *d_out) {
+    if (n_lines == 0) return SPEC_OK;
+    const bool f64 = fmt >= SPEC_OUT_DB20_F64 || dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
+    if (!plan_supported(log2n, f64))
+        return fail(c, SPEC_EUNSUPPORTED, "nfft = 2^%d is not supported in %s yet", log2n, f64 ? "fp64" : "fp32");
+    WfArgs a{};
+    a.iq = d_first;
+    a.hop = hop;
+    a.bps = spec_bytes_per_sample(dt);
+    a.kind = kind_of(dt, c->flags);
+    a.be = is_be(dt);
+    a.out_fmt = (int)fmt;
+    spec_status st = get_twiddles(c, log2n, f64, &a.tw);
+    if (st != SPEC_OK) return st;
+    st = get_window(c, log2n, f64, window, &a.win, nullptr, nullptr);
+    if (st != SPEC_OK) return st;
+    const int lpw = plan_lpw(log2n);
+    const uint64_t out_esz = fmt >= SPEC_OUT_DB20_F64 ? 8 : 4, nfft = 1ull << log2n;
+    // one launch covers at most 2^31 - 1 workgroups; split very long recordings
+    uint64_t done = 0;
+    while (done < n_lines) {
+        const uint64_t rem = n_lines - done;
+        a.lines_per_wg = pick_lines_per_wg(rem, lpw);
+        const uint64_t max_lines = (uint64_t)a.lines_per_wg * 0x7FFFFFFFull;
+        a.n_lines = rem < max_lines ? rem : max_lines;
+        a.iq = d_first + done * (uint64_t)hop * a.bps;
+        a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+        hipError_t e = f64 ? launch_spectro_f64(a, log2n, c->stream) : launch_spectro_f32(a, log2n, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "spectrogram launch: %s", hipGetErrorString(e));
+        done += a.n_lines;
+    }
+    return SPEC_OK;
+}
+
+static spec_status check_common(spec_ctx *c, const void *iq, const void *out, int dt, uint32_t nfft, uint32_t hop,
+                                int window, int *log2n) {
+    if (!c) return SPEC_EINVAL;
+    if (!iq || !out) return fail(c, SPEC_EINVAL, "null buffer");
+    if (!dtype_valid(dt)) return fail(c, SPEC_EINVAL, "bad spec_dtype %d", dt);
+    if (nfft == 0 || (nfft & (nfft - 1)) != 0)  // commons-math3 throws for these (SS:29)
+        return fail(c, SPEC_EINVAL, "nfft = %u is not a power of two", nfft);
+    if (hop == 0) return fail(c, SPEC_EINVAL, "hop must be >= 1");
+    if (window != SPEC_WIN_RECT && window != SPEC_WIN_HANN) return fail(c, SPEC_EINVAL, "bad window %d", window);
+    *log2n = ilog2(nfft);
+    return SPEC_OK;
+}
+
+extern "C" {
+
+spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
+                           spec_dtype dt, uint32_t nfft, uint32_t hop, uint64_t n_lines, spec_window window,
+                           spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device) {
+    int log2n = 0;
+    spec_status st = check_common(c, iq, out, dt, nfft, hop, window, &log2n);
+    if (st != SPEC_OK) return st;
+    if (out_fmt < SPEC_OUT_DB20_F32 || out_fmt > SPEC_OUT_POW_F64) return fail(c, SPEC_EINVAL, "bad out_fmt %d", out_fmt);
+    if (n_lines == 0) return SPEC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t bps = spec_bytes_per_sample(dt), out_esz = out_fmt >= SPEC_OUT_DB20_F64 ? 8 : 4;
+    // MainController.java:987 -- lines whose last byte is inside the buffer
+    uint64_t n_valid = spec_count_lines(n_bytes, start_byte, dt, nfft, hop);
+    if (n_valid > n_lines) n_valid = n_lines;
+    const bool f64 = out_fmt >= SPEC_OUT_DB20_F64 || dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
+    if (n_valid && !plan_supported(log2n, f64))
+        return fail(c, SPEC_EUNSUPPORTED, "nfft = %u is not supported in %s yet", nfft, f64 ? "fp64" : "fp32");
+
+    if (iq_on_device && out_on_device) {
+        const uint8_t *first = static_cast<const uint8_t *>(iq) + start_byte;
+        if (n_valid && (reinterpret_cast<uintptr_t>(first) % component_bytes(dt)) != 0)
+            return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
+        st = run_lines(c, first, dt, log2n, hop, n_valid, window, out_fmt, out);
+        if (st != SPEC_OK) return st;
+        if (n_valid < n_lines) {  // MC:994-998
+            hipError_t e = launch_fill(static_cast<uint8_t *>(out) + n_valid * nfft * out_esz, (n_lines - n_valid) * nfft,
+                                       eof_fill, out_esz == 8, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "fill launch: %s", hipGetErrorString(e));
+        }
+        return SPEC_OK;
+    }
+
+    // staged path: walk the valid lines in chunks that fit the staging buffers
+    const uint64_t chunk_cap = 256ull << 20;
+    uint64_t lines_per_chunk = chunk_cap / (nfft * out_esz);
+    const uint64_t by_in = chunk_cap > nfft * bps ? (chunk_cap - nfft * bps) / ((uint64_t)hop * bps) + 1 : 1;
+    if (by_in < lines_per_chunk) lines_per_chunk = by_in;
+    if (lines_per_chunk == 0) lines_per_chunk = 1;
+    for (uint64_t l0 = 0; l0 < n_valid; l0 += lines_per_chunk) {
+        const uint64_t nl = (n_valid - l0 < lines_per_chunk) ? n_valid - l0 : lines_per_chunk;
+        const uint64_t in_off = start_byte + l0 * hop * bps, in_len = ((nl - 1) * hop + nfft) * bps;
+        const uint8_t *d_in;
+        if (iq_on_device) {
+            d_in = static_cast<const uint8_t *>(iq) + in_off;
+            if (reinterpret_cast<uintptr_t>(d_in) % component_bytes(dt) != 0)
+                return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
+        } else {
+            st = grow(c, &c->stage_in, &c->stage_in_bytes, in_len);
+            if (st != SPEC_OK) return st;
+            HIP_TRY(c, hipMemcpyAsync(c->stage_in, static_cast<const uint8_t *>(iq) + in_off, in_len,
+                                      hipMemcpyHostToDevice, c->stream));
+            d_in = static_cast<const uint8_t *>(c->stage_in);
+        }
+        void *d_out;
+        if (out_on_device) {
+            d_out = static_cast<uint8_t *>(out) + l0 * nfft * out_esz;
+        } else {
+            st = grow(c, &c->stage_out, &c->stage_out_bytes, nl * nfft * out_esz);
+            if (st != SPEC_OK) return st;
+            d_out = c->stage_out;
+        }
+        st = run_lines(c, d_in, dt, log2n, hop, nl, window, out_fmt, d_out);
+        if (st != SPEC_OK) return st;
+        if (!out_on_device)
+            HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t *>(out) + l0 * nfft * out_esz, d_out, nl * nfft * out_esz,
+                                      hipMemcpyDeviceToHost, c->stream));
+        if (!iq_on_device || !out_on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (n_valid < n_lines) {  // MC:994-998
+        const uint64_t n = (n_lines - n_valid) * nfft;
+        if (out_on_device) {
+            hipError_t e = launch_fill(static_cast<uint8_t *>(out) + n_valid * nfft * out_esz, n, eof_fill, out_esz == 8,
+                                       c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "fill launch: %s", hipGetErrorString(e));
+        } else if (out_esz == 8) {
+            double *p = static_cast<double *>(out) + n_valid * nfft;
+            for (uint64_t i = 0; i < n; ++i) p[i] = eof_fill;
+        } else {
+            float *p = static_cast<float *>(out) + n_valid * nfft;
+            for (uint64_t i = 0; i < n; ++i) p[i] = (float)eof_fill;
+        }
+    }
+    return SPEC_OK;
+}
+
+spec_status spec_compute_magnitudes(spec_ctx *c, const void *buffer, uint64_t capacity, int64_t start_byte,
+                                    uint32_t nfft, const char *datatype, int big_endian, double *out) {
+    if (!c) return SPEC_EINVAL;
+    if (!buffer || !out || !datatype) return fail(c, SPEC_EINVAL, "null argument");
+    if (nfft == 0 || (nfft & (nfft - 1)) != 0) return fail(c, SPEC_EINVAL, "nfft = %u is not a power of two", nfft);
+    // datatype: startsWith rules of SS:35-38; byte order is the buffer's (SMH:87-91)
+    spec_dtype dt = spec_dtype_from_sigmf(datatype);
+    switch (dt) {
+    case SPEC_DT_CI16_LE: case SPEC_DT_CI16_BE: dt = big_endian ? SPEC_DT_CI16_BE : SPEC_DT_CI16_LE; break;
+    case SPEC_DT_CF32_LE: case SPEC_DT_CF32_BE: dt = big_endian ? SPEC_DT_CF32_BE : SPEC_DT_CF32_LE; break;
+    case SPEC_DT_CF64_LE: case SPEC_DT_CF64_BE: dt = big_endian ? SPEC_DT_CF64_BE : SPEC_DT_CF64_LE; break;
+    default: break;
+    }
+    // the reference's service reads only what its decode branch touches: nothing
+    // for an unknown datatype (SS:60-63), else nfft * bytes-per-IQ from startByte
+    const bool reads = kind_of(dt, c->flags) != K_ZERO;
+    const uint64_t span = (uint64_t)nfft * spec_bytes_per_sample(dt);
+    if (reads && (start_byte < 0 || (uint64_t)start_byte + span > capacity))
+        return fail(c, SPEC_ERANGE, "IndexOutOfBounds: bytes [%lld, +%llu) of %llu", (long long)start_byte,
+                    (unsigned long long)span, (unsigned long long)capacity);
+    if (!reads) {  // flat 20 log10(1e-10) = -200 dB, no bytes touched
+        for (uint32_t i = 0; i < nfft; ++i) out[i] = -200.0;
+        return SPEC_OK;
+    }
+    return spec_waterfall(c, buffer, 0, capacity, (uint64_t)start_byte, dt, nfft, nfft, 1, SPEC_WIN_RECT,
+                          SPEC_OUT_DB20_F64, -150.0, out, 0);
+}
+
+spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
+                           uint64_t psd_stride_bytes, uint32_t n_psd, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                           uint32_t n_seg, spec_window window, spec_psd_scaling scaling, double fs, int db,
+                           double *freq_out, float *psd_out, int out_on_device) {
+    int log2n = 0;
+    spec_status st = check_common(c, iq, psd_out, dt, nfft, hop, window, &log2n);
+    if (st != SPEC_OK) return st;
+    if (n_seg == 0 || n_psd == 0) return fail(c, SPEC_EINVAL, "n_seg and n_psd must be >= 1");
+    if (!(fs > 0)) return fail(c, SPEC_EINVAL, "fs must be positive");
+    if (scaling != SPEC_PSD_DENSITY && scaling != SPEC_PSD_SPECTRUM) return fail(c, SPEC_EINVAL, "bad scaling");
+    if (dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE || !plan_supported(log2n, false))
+        return fail(c, SPEC_EUNSUPPORTED, "Welch PSD: nfft = %u / cf64 not supported yet", nfft);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t bps = spec_bytes_per_sample(dt);
+    const uint64_t span = ((uint64_t)(n_seg - 1) * hop + nfft) * bps;
+    const uint64_t total = (uint64_t)(n_psd - 1) * psd_stride_bytes + span;
+    if (start_byte > n_bytes || total > n_bytes - start_byte)
+        return fail(c, SPEC_ERANGE, "Welch PSD needs bytes [%llu, +%llu) of %llu", (unsigned long long)start_byte,
+                    (unsigned long long)total, (unsigned long long)n_bytes);
+    if (n_psd > 1 && psd_stride_bytes % component_bytes(dt) != 0)
+        return fail(c, SPEC_EINVAL, "psd_stride_bytes must be a multiple of the component size");
+
+    const uint8_t *d_in;
+    if (iq_on_device) {
+        d_in = static_cast<const uint8_t *>(iq) + start_byte;
+        if (reinterpret_cast<uintptr_t>(d_in) % component_bytes(dt) != 0)
+            return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
+    } else {
+        st = grow(c, &c->stage_in, &c->stage_in_bytes, total);
+        if (st != SPEC_OK) return st;
+        HIP_TRY(c, hipMemcpyAsync(c->stage_in, static_cast<const uint8_t *>(iq) + start_byte, total,
+                                  hipMemcpyHostToDevice, c->stream));
+        d_in = static_cast<const uint8_t *>(c->stage_in);
+    }
+    WelchArgs a{};
+    a.iq = d_in;
+    a.psd_stride_bytes = psd_stride_bytes;
+    a.n_psd = n_psd;
+    a.n_seg = n_seg;
+    a.hop = hop;
+    a.bps = (uint32_t)bps;
+    a.kind = kind_of(dt, c->flags);
+    a.be = is_be(dt);
+    st = get_twiddles(c, log2n, false, &a.tw);
+    if (st != SPEC_OK) return st;
+    double s1 = 0, s2 = 0;
+    st = get_window(c, log2n, false, window, &a.win, &s1, &s2);
+    if (st != SPEC_OK) return st;
+    const int lpw = plan_lpw(log2n);
+    // enough workgroups to fill the chip when few PSDs are requested
+    uint32_t chunks = (n_seg + lpw - 1) / lpw;  // at most one group of LPW segments per workgroup
+    const uint32_t want = n_psd >= 2048 ? 1 : (2048 + n_psd - 1) / n_psd;
+    if (chunks > want) chunks = want;
+    a.segs_per_wg = ((n_seg + chunks - 1) / chunks + lpw - 1) / lpw * lpw;
+    a.n_chunks = (n_seg + a.segs_per_wg - 1) / a.segs_per_wg;
+    const uint32_t n_slabs = a.n_chunks * lpw;
+    st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)n_psd * n_slabs * nfft * sizeof(float));
+    if (st != SPEC_OK) return st;
+    a.partial = static_cast<float *>(c->scratch);
+    float *d_out = psd_out;
+    if (!out_on_device) {
+        st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * sizeof(float));
+        if (st != SPEC_OK) return st;
+        d_out = static_cast<float *>(c->stage_out);
+    }
+    hipError_t e = launch_welch_f32(a, log2n, c->stream);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch launch: %s", hipGetErrorString(e));
+    const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
+    e = launch_welch_finalize(a.partial, n_psd, n_slabs, nfft, norm, db, d_out, c->stream);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch finalize launch: %s", hipGetErrorString(e));
+    if (!out_on_device) {
+        HIP_TRY(c, hipMemcpyAsync(psd_out, d_out, (size_t)n_psd * nfft * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if (!iq_on_device) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // staging buffer may be reused by the next call
+    }
+    if (freq_out)  // AnalysisDialogController.java:324-328 adds centerFreq to this axis
+        for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
+    return SPEC_OK;
+}
+
+spec_status spec_synth_iq(spec_ctx *c, void *dev_out, spec_dtype dt, uint64_t seed, uint64_t first_sample,
+                          uint64_t n_samples) {
+    if (!c) return SPEC_EINVAL;
+    if (!dev_out) return fail(c, SPEC_EINVAL, "null buffer");
+    if (!dtype_valid(dt) || dt == SPEC_DT_UNKNOWN) return fail(c, SPEC_EINVAL, "bad spec_dtype %d", dt);
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipError_t e = launch_synth(dev_out, kind_of(dt, 0), is_be(dt), seed, first_sample, n_samples, c->stream);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "synth launch: %s", hipGetErrorString(e));
+    return SPEC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// spec_internal.h -- host-side interface between the C ABI (spec_capi.hip) and
+// the kernel translation units.  Not installed; include/specgpu.h is the public
+// header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace specgpu {
+
+// out_fmt values mirror spec_out_fmt
+enum : int { OUT_DB20_F32 = 0, OUT_POW_F32 = 1, OUT_DB20_F64 = 2, OUT_POW_F64 = 3 };
+
+// Arguments of one spectrogram launch.  `iq` already points at the first byte
+// of line 0; every line is known to be inside the buffer (the host clips).
+struct WfArgs {
+    const uint8_t *iq;
+    uint64_t n_lines;
+    uint32_t hop;        // samples between line starts
+    uint32_t bps;        // bytes per IQ pair
+    int kind;            // K_* decode kind (spec_fft.h)
+    int be;              // big-endian components
+    const void *tw;      // cx<R>[N] twiddle table W_N^m
+    const void *win;     // R[N] window or nullptr (rectangular)
+    void *out;           // n_lines x N, row-major
+    int out_fmt;
+    uint32_t lines_per_wg;  // contiguous lines handled by one workgroup (multiple of LPW)
+};
+
+// Arguments of one Welch partial-sum launch: PSD b, chunk c accumulates
+// segments [c*segs_per_wg, ...) into partial[(b*n_chunks + c)*LPW + q][N].
+struct WelchArgs {
+    const uint8_t *iq;          // first byte of segment 0 of PSD 0
+    uint64_t psd_stride_bytes;
+    uint32_t n_psd, n_seg, n_chunks, segs_per_wg;
+    uint32_t hop, bps;
+    int kind, be;
+    const void *tw, *win;
+    float *partial;             // [n_psd][n_chunks*LPW][N] unshifted power sums (fp32)
+};
+
+int plan_lpw(int log2n);  // lines a workgroup transforms concurrently
+bool plan_supported(int log2n, bool f64);
+
+hipError_t launch_spectro_f32(const WfArgs &a, int log2n, hipStream_t s);
+hipError_t launch_spectro_f64(const WfArgs &a, int log2n, hipStream_t s);
+hipError_t launch_welch_f32(const WelchArgs &a, int log2n, hipStream_t s);
+
+hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);
+hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs,
+                                 uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);
+hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t first_sample,
+                        uint64_t n_samples, hipStream_t s);
+
+}  // namespace specgpu

@@ -1,0 +1,104 @@
+// spec_misc.hip -- small helper kernels: EOF fill, Welch slab reduction,
+// synthetic IQ generator.
+#include "spec_fft.h"
+#include "spec_internal.h"
+
+namespace specgpu {
+
+// MainController.java:994-998 -- lines past the end of the recording
+template <typename T> __global__ void fill_kernel(T *out, uint64_t n, T value) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = value;
+}
+
+hipError_t launch_fill(void *out, uint64_t n, double value, int is_f64, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    if (is_f64) hipLaunchKernelGGL(fill_kernel<double>, dim3(blocks), dim3(256), 0, s, static_cast<double *>(out), n, value);
+    else hipLaunchKernelGGL(fill_kernel<float>, dim3(blocks), dim3(256), 0, s, static_cast<float *>(out), n, (float)value);
+    return hipGetLastError();
+}
+
+// Sum the partial slabs of each PSD in a fixed order (bitwise reproducible),
+// scale, fftshift, optional 10 log10(P + 1e-20).
+__global__ void welch_finalize_kernel(const float *__restrict__ partial, uint32_t n_slabs, uint32_t nfft,
+                                      double norm, int db, float *__restrict__ psd_out) {
+    const uint32_t psd = blockIdx.y;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfft) return;
+    const float *p = partial + (uint64_t)psd * n_slabs * nfft + k;
+    double acc = 0;
+    for (uint32_t sl = 0; sl < n_slabs; ++sl) acc += (double)p[(uint64_t)sl * nfft];
+    const double v = acc * norm;
+    const uint32_t ks = (k + nfft / 2) & (nfft - 1);
+    psd_out[(uint64_t)psd * nfft + ks] = db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+}
+
+hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs, uint32_t nfft,
+                                 double norm, int db, float *psd_out, hipStream_t s) {
+    hipLaunchKernelGGL(welch_finalize_kernel, dim3((nfft + 255) / 256, n_psd), dim3(256), 0, s, partial, n_slabs,
+                       nfft, norm, db, psd_out);
+    return hipGetLastError();
+}
+
+// ---- synthetic IQ: two tones + Gaussian noise, counter based ----------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+__global__ void synth_kernel(uint8_t *out, int kind, int be, uint64_t seed, uint64_t first, uint64_t n) {
+    constexpr uint32_t INC1 = 528280977u;   // round(0.123 * 2^32)
+    constexpr uint32_t INC2 = 2963527434u;  // round((1 - 0.31) * 2^32)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t s = first + i;
+        const uint64_t a = splitmix64(seed ^ (2 * s)), b = splitmix64(seed ^ (2 * s + 1));
+        const float u1 = ((float)(uint32_t)(a >> 40) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(uint32_t)(b >> 40) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = 0.05f * sqrtf(-2.0f * logf(u1));
+        const uint32_t p1 = (uint32_t)(s * (uint64_t)INC1), p2 = (uint32_t)(s * (uint64_t)INC2);
+        float sn, cn, s1, c1, s2, c2;
+        sincospif(2.0f * u2, &sn, &cn);
+        sincospif((float)((double)p1 * (2.0 / 4294967296.0)), &s1, &c1);
+        sincospif((float)((double)p2 * (2.0 / 4294967296.0)), &s2, &c2);
+        float v[2] = {r * cn + 0.5f * c1 + 0.1f * c2, r * sn + 0.5f * s1 + 0.1f * s2};
+        for (int c = 0; c < 2; ++c) {
+            const float x = v[c], xc = fminf(1.0f, fmaxf(-1.0f, x));
+            switch (kind) {
+            case K_CF32: {
+                uint32_t u = __float_as_uint(x);
+                if (be) u = __builtin_bswap32(u);
+                reinterpret_cast<uint32_t *>(out)[2 * i + c] = u;
+                break;
+            }
+            case K_CF64: {
+                uint64_t u = (uint64_t)__double_as_longlong((double)x);
+                if (be) u = __builtin_bswap64(u);
+                reinterpret_cast<uint64_t *>(out)[2 * i + c] = u;
+                break;
+            }
+            case K_CI16: {
+                uint16_t u = (uint16_t)(int16_t)__float2int_rn(32767.0f * xc);
+                if (be) u = __builtin_bswap16(u);
+                reinterpret_cast<uint16_t *>(out)[2 * i + c] = u;
+                break;
+            }
+            case K_CI8: out[2 * i + c] = (uint8_t)(int8_t)__float2int_rn(127.0f * xc); break;
+            case K_CU8: out[2 * i + c] = (uint8_t)__float2int_rn(127.5f + 127.0f * xc); break;
+            default: break;
+            }
+        }
+    }
+}
+
+hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t first, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 65536 ? 65536 : (n + 255) / 256);
+    hipLaunchKernelGGL(synth_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint8_t *>(out), kind, be, seed,
+                       first, n);
+    return hipGetLastError();
+}
+
+}  // namespace specgpu

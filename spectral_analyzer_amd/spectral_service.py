@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's ``SpectralService`` for the GPU path.
+
+Reference (paths under src/main/java/net/kcundercover/spectral_analyzer/):
+  * ``services/SpectralService.java:33-85``  computeMagnitudes -- one line
+  * ``controllers/MainController.java:980-999``  the slice loop that calls it
+  * ``controllers/AnalysisDialogController.java:303-313``  the Welch PSD call
+
+The class keeps the reference's method name, argument order and error
+behaviour (``compute_magnitudes(buffer, start_byte, nfft, datatype)``) and adds
+the batched calls the device boundary wants (``compute_waterfall``,
+``welch_psd``).  Everything numeric happens in libspecgpu.so through the C ABI
+of ``include/specgpu.h``; PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+_ERRORS = {
+    L.SPEC_EINVAL: ValueError,            # IllegalArgumentException
+    L.SPEC_ERANGE: IndexError,            # IndexOutOfBoundsException
+    L.SPEC_EDEVICE: RuntimeError,
+    L.SPEC_ENOMEM: MemoryError,
+    L.SPEC_EUNSUPPORTED: NotImplementedError,
+}
+
+_OUT_NP = {L.OUT_DB20_F32: np.float32, L.OUT_POW_F32: np.float32,
+           L.OUT_DB20_F64: np.float64, L.OUT_POW_F64: np.float64}
+
+
+def dtype_from_sigmf(datatype: str) -> int:
+    """SigMF datatype string -> spec_dtype (startsWith rules of SS:35-38)."""
+    return int(L.load().spec_dtype_from_sigmf(datatype.encode()))
+
+
+def bytes_per_sample(datatype: str) -> int:
+    """``Global.getBytesPerSample()`` (sigmf/Global.java:67-79)."""
+    return int(L.load().spec_bytes_per_sample(dtype_from_sigmf(datatype)))
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _host_bytes(buffer) -> np.ndarray:
+    if isinstance(buffer, np.ndarray):
+        a = buffer.reshape(-1).view(np.uint8)
+    else:
+        a = np.frombuffer(buffer, dtype=np.uint8)
+    return np.ascontiguousarray(a)
+
+
+class SpectralService:
+    """GPU-backed drop-in for the reference ``SpectralService`` singleton."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None, ref_cf64_zero: bool = False):
+        self._lib = L.load()
+        self._ctx = C.c_void_p()
+        flags = L.FLAG_REF_CF64_ZERO if ref_cf64_zero else 0
+        st = self._lib.spec_create(int(device), C.c_void_p(stream) if stream else None, flags,
+                                   C.byref(self._ctx))
+        if st != L.SPEC_OK:
+            msg = self._lib.spec_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise _ERRORS.get(st, RuntimeError)(msg)
+        self.device = int(device)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.spec_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, st: int) -> None:
+        if st != L.SPEC_OK:
+            raise _ERRORS.get(st, RuntimeError)(self._lib.spec_last_error(self._ctx).decode())
+
+    def synchronize(self) -> None:
+        self._check(self._lib.spec_sync(self._ctx))
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.spec_stream(self._ctx) or 0)
+
+    # -- SpectralService.computeMagnitudes (SS:33-85) -----------------------
+    def compute_magnitudes(self, buffer, start_byte: int, nfft: int, datatype: str,
+                           big_endian: Optional[bool] = None) -> np.ndarray:
+        """One spectrogram line as ``double[nfft]`` (index 0 = -fs/2).
+
+        ``buffer`` stands for the ``MappedByteBuffer``; its byte order defaults
+        to what ``SigMfHelper.load`` would set for ``datatype``
+        (sigmf/SigMfHelper.java:87-91: "_le" suffix -> little endian, else big).
+        Raises ValueError for a non power-of-two nfft (commons-math3's
+        MathIllegalArgumentException) and IndexError when the slice leaves the
+        buffer (the ByteBuffer getters' IndexOutOfBoundsException).
+        """
+        b = _host_bytes(buffer)
+        if big_endian is None:
+            big_endian = not datatype.endswith("_le")
+        out = np.empty(int(nfft) if nfft > 0 else 0, dtype=np.float64)
+        self._check(self._lib.spec_compute_magnitudes(
+            self._ctx, b.ctypes.data, b.size, int(start_byte), int(nfft) & 0xFFFFFFFF,
+            datatype.encode(), int(bool(big_endian)), out.ctypes.data))
+        return out
+
+    # -- MainController.updateDisplay slice loop (MC:980-999), batched ------
+    def compute_waterfall(self, buffer, start_byte: int, nfft: int, datatype: str,
+                          n_lines: int, hop: Optional[int] = None, window: int = L.WIN_RECT,
+                          out_fmt: int = L.OUT_DB20_F32, eof_fill: float = -150.0, out=None):
+        """``n_lines`` lines, ``hop`` samples apart (reference: hop = nfft).
+
+        ``buffer`` is host bytes (numpy / bytes / mmap) or a torch uint8 CUDA
+        tensor; the result has the same residency (numpy array, or a torch
+        tensor on the context's device).  Lines past the end of the buffer are
+        ``eof_fill`` (MC:994-998).
+        """
+        hop = int(nfft if hop is None else hop)
+        dt = dtype_from_sigmf(datatype)
+        np_dt = _OUT_NP[out_fmt]
+        if _is_torch(buffer):
+            import torch
+            if not buffer.is_cuda or buffer.dtype != torch.uint8 or not buffer.is_contiguous():
+                raise ValueError("device buffer must be a contiguous CUDA uint8 tensor")
+            t_dt = torch.float32 if np_dt is np.float32 else torch.float64
+            if out is None:
+                out = torch.empty((int(n_lines), int(nfft)), dtype=t_dt, device=buffer.device)
+            elif out.dtype != t_dt or out.numel() < n_lines * nfft or not out.is_contiguous():
+                raise ValueError("out tensor has the wrong dtype/size")
+            self._check(self._lib.spec_waterfall(
+                self._ctx, buffer.data_ptr(), 1, buffer.numel(), int(start_byte), dt, int(nfft), hop,
+                int(n_lines), window, out_fmt, float(eof_fill), out.data_ptr(), 1))
+            return out
+        b = _host_bytes(buffer)
+        res = np.empty((int(n_lines), int(nfft)), dtype=np_dt)
+        self._check(self._lib.spec_waterfall(
+            self._ctx, b.ctypes.data, 0, b.size, int(start_byte), dt, int(nfft), hop, int(n_lines),
+            window, out_fmt, float(eof_fill), res.ctypes.data, 0))
+        return res
+
+    def count_lines(self, n_bytes: int, start_byte: int, datatype: str, nfft: int, hop: int) -> int:
+        return int(self._lib.spec_count_lines(int(n_bytes), int(start_byte), dtype_from_sigmf(datatype),
+                                              int(nfft), int(hop)))
+
+    # -- PowerSpectralDensity.calculatePsdWelch call site (ADC:303-313) -----
+    def welch_psd(self, buffer, start_byte: int, datatype: str, fs: float, nfft: int = 8192,
+                  hop: Optional[int] = None, n_seg: Optional[int] = None, window: int = L.WIN_HANN,
+                  scaling: int = L.PSD_DENSITY, db: bool = False, n_psd: int = 1,
+                  psd_stride_bytes: int = 0) -> Tuple[np.ndarray, object]:
+        """Welch PSD; returns ``(freq[nfft], psd[n_psd, nfft])`` like the two
+        rows the reference plots (ADC:324-328).  ``hop`` defaults to nfft/2 and
+        ``n_seg`` to every whole segment available after ``start_byte``."""
+        hop = int(nfft // 2 if hop is None else hop)
+        dt = dtype_from_sigmf(datatype)
+        on_dev = _is_torch(buffer)
+        n_bytes = buffer.numel() if on_dev else None
+        if on_dev:
+            import torch
+            if not buffer.is_cuda or buffer.dtype != torch.uint8 or not buffer.is_contiguous():
+                raise ValueError("device buffer must be a contiguous CUDA uint8 tensor")
+            ptr = buffer.data_ptr()
+        else:
+            b = _host_bytes(buffer)
+            n_bytes, ptr = b.size, b.ctypes.data
+        if n_seg is None:
+            n_seg = int(self._lib.spec_count_lines(n_bytes, int(start_byte), dt, int(nfft), hop))
+        freq = np.empty(int(nfft), dtype=np.float64)
+        if on_dev:
+            psd = torch.empty((int(n_psd), int(nfft)), dtype=torch.float32, device=buffer.device)
+            out_ptr = psd.data_ptr()
+        else:
+            psd = np.empty((int(n_psd), int(nfft)), dtype=np.float32)
+            out_ptr = psd.ctypes.data
+        self._check(self._lib.spec_welch_psd(
+            self._ctx, ptr, int(on_dev), n_bytes, int(start_byte), int(psd_stride_bytes), int(n_psd), dt,
+            int(nfft), hop, int(n_seg), window, scaling, float(fs), int(db), freq.ctypes.data, out_ptr,
+            int(on_dev)))
+        return freq, psd
+
+    # -- synthetic recording (bench / tests) --------------------------------
+    def synth_iq(self, datatype: str, seed: int, first_sample: int, n_samples: int, out=None):
+        """Counter-based synthetic IQ generated on the device (uint8 tensor)."""
+        import torch
+        nbytes = int(n_samples) * bytes_per_sample(datatype)
+        if out is None:
+            out = torch.empty(nbytes, dtype=torch.uint8, device="cuda:%d" % self.device)
+        self._check(self._lib.spec_synth_iq(self._ctx, out.data_ptr(), dtype_from_sigmf(datatype),
+                                            int(seed), int(first_sample), int(n_samples)))
+        return out
