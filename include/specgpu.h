@@ -102,6 +102,13 @@ spec_status spec_sync(spec_ctx *ctx);
 /* The hipStream_t the context launches on (for callers that time with HIP events). */
 void *spec_stream(const spec_ctx *ctx);
 
+/* Tuning / testing knobs (not needed for normal use):
+ *   "force_generic" = 1  route every request through the generic kernels
+ *   "lines_per_wg"  = n  consecutive lines walked by one workgroup (0 = automatic)
+ *   "variant"       = v  kernel variant bits of the tuned 4096-point path
+ *                        (bit 0: non-temporal loads/stores) */
+spec_status spec_set_option(spec_ctx *ctx, const char *key, int64_t value);
+
 /* ---- datatype table ------------------------------------------------------ */
 
 /* SigMF datatype string -> spec_dtype with the reference's startsWith rules

@@ -31,6 +31,9 @@ struct spec_ctx {
     void *stage_in = nullptr;  size_t stage_in_bytes = 0;
     void *stage_out = nullptr; size_t stage_out_bytes = 0;
     void *scratch = nullptr;   size_t scratch_bytes = 0;
+    // tuning / testing knobs (spec_set_option)
+    int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_variant = 0;
+    int n_cu = 256;
 };
 
 static thread_local std::string g_create_err;
@@ -137,6 +140,7 @@ spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx *
     if (!c) return fail(nullptr, SPEC_ENOMEM, "spec_create: out of host memory");
     c->device = device;
     c->flags = flags;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, SPEC_EDEVICE, "hipSetDevice(%d) failed", device); }
     if (hip_stream) {
         c->stream = static_cast<hipStream_t>(hip_stream);
@@ -172,6 +176,16 @@ spec_status spec_sync(spec_ctx *c) {
 }
 
 void *spec_stream(const spec_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
+
+spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
+    if (!c) return SPEC_EINVAL;
+    if (!key) return fail(c, SPEC_EINVAL, "spec_set_option: null key");
+    if (!strcmp(key, "force_generic")) c->opt_force_generic = value;
+    else if (!strcmp(key, "lines_per_wg")) c->opt_lines_per_wg = value < 0 ? 0 : value;
+    else if (!strcmp(key, "variant")) c->opt_variant = value;
+    else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
+    return SPEC_OK;
+}
 
 }  // extern "C"
 
@@ -280,16 +294,30 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     if (st != SPEC_OK) return st;
     const int lpw = plan_lpw(log2n);
     const uint64_t out_esz = fmt >= SPEC_OUT_DB20_F64 ? 8 : 4, nfft = 1ull << log2n;
+    const bool tuned = !f64 && !c->opt_force_generic && tuned4096_applicable(a, log2n);
     // one launch covers at most 2^31 - 1 workgroups; split very long recordings
     uint64_t done = 0;
     while (done < n_lines) {
         const uint64_t rem = n_lines - done;
-        a.lines_per_wg = pick_lines_per_wg(rem, lpw);
+        if (c->opt_lines_per_wg > 0) {
+            a.lines_per_wg = (uint32_t)((c->opt_lines_per_wg + lpw - 1) / lpw * lpw);
+        } else if (tuned) {
+            // equal runs for the workgroups each CU holds (LDS request pins that number); short
+            // inputs still get runs of 16 lines so that overlap reuse pays
+            const uint64_t resident = (uint64_t)c->n_cu * tuned4096_wgs_per_cu((int)c->opt_variant);
+            uint64_t per = (rem + resident - 1) / resident;
+            if (per < 16) per = 16;
+            a.lines_per_wg = (uint32_t)per;
+        } else {
+            a.lines_per_wg = pick_lines_per_wg(rem, lpw);
+        }
         const uint64_t max_lines = (uint64_t)a.lines_per_wg * 0x7FFFFFFFull;
         a.n_lines = rem < max_lines ? rem : max_lines;
         a.iq = d_first + done * (uint64_t)hop * a.bps;
         a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
-        hipError_t e = f64 ? launch_spectro_f64(a, log2n, c->stream) : launch_spectro_f32(a, log2n, c->stream);
+        hipError_t e = tuned ? launch_spectro4096(a, (int)c->opt_variant, c->stream)
+                       : f64 ? launch_spectro_f64(a, log2n, c->stream)
+                             : launch_spectro_f32(a, log2n, c->stream);
         if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "spectrogram launch: %s", hipGetErrorString(e));
         done += a.n_lines;
     }

@@ -94,6 +94,10 @@ class SpectralService:
     def synchronize(self) -> None:
         self._check(self._lib.spec_sync(self._ctx))
 
+    def set_option(self, key: str, value: int) -> None:
+        """Tuning / testing knobs of ``spec_set_option`` (include/specgpu.h)."""
+        self._check(self._lib.spec_set_option(self._ctx, key.encode(), int(value)))
+
     @property
     def stream(self) -> int:
         return int(self._lib.spec_stream(self._ctx) or 0)

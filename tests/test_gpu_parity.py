@@ -3,7 +3,11 @@ same seeded inputs.  Tolerances are the ones stated in SURVEY.md 8(c):
 
 fp32 pipeline (reference is fp64):  with M = max_k |X[k]| of the line,
     * every bin:                 | |X|_gpu - |X|_ref |  <=  4e-6 * M * log2(N)
-    * bins with |X| >= 1e-4 * M: | dB_gpu - dB_ref |    <=  2e-3 dB
+    * bins with |X| >= 1e-3 * M: | dB_gpu - dB_ref |    <=  2e-3 dB
+    * bins with |X| >= 1e-4 * M: | dB_gpu - dB_ref |    <=  2e-2 dB
+  (the fp32 FFT adds a noise floor of about 3 eps sqrt(log2 N) ||x||_2 rms to every
+  bin -- measured with tools/errstats.py -- so the dB error of a bin grows as the bin
+  gets weaker; SURVEY 8(c) guessed 2e-3 dB down to 1e-4 M before anything was measured)
 fp64 pipeline (DB20_F64 / cf64): | dB_gpu - dB_ref | <= 1e-9 dB on bins with |X| >= 1e-9 * M
 """
 import numpy as np
@@ -23,9 +27,9 @@ def check_fp32(db_gpu, db_ref, nfft):
     M = mag_r.max(axis=1, keepdims=True)
     lin_err = np.abs(mag_g - mag_r) / (M * np.log2(nfft))
     assert lin_err.max() <= 4e-6, "linear error %.3g > 4e-6 M log2 N" % lin_err.max()
-    strong = mag_r >= 1e-4 * M
-    db_err = np.abs(db_gpu.astype(np.float64) - db_ref)[strong]
-    assert db_err.max() <= 2e-3, "dB error %.3g on strong bins" % db_err.max()
+    db_abs = np.abs(db_gpu.astype(np.float64) - db_ref)
+    assert db_abs[mag_r >= 1e-3 * M].max() <= 2e-3, "dB error %.3g on bins >= 1e-3 M" % db_abs[mag_r >= 1e-3 * M].max()
+    assert db_abs[mag_r >= 1e-4 * M].max() <= 2e-2, "dB error %.3g on bins >= 1e-4 M" % db_abs[mag_r >= 1e-4 * M].max()
 
 
 def check_fp64(db_gpu, db_ref):
@@ -45,7 +49,44 @@ def test_waterfall_matches_oracle(svc, oracle, datatype, nfft):
     ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines)
     got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop)
     assert got.shape == (n_lines, nfft)
-    if datatype.startswith("cf64"):
-        check_fp64(got.astype(np.float64), ref) if False else check_fp32(got, ref, nfft)
-    else:
-        check_fp32(got, ref, nfft)
+    check_fp32(got, ref, nfft)   # cf64 input runs in fp64 but DB20_F32 output rounds to float
+
+
+# the tuned 4096-point kernel (spec_k_tuned.hip): every variant, all three hops, runs long
+# enough to exercise the register sliding window, both datatypes, with and without window
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7])
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le"])
+def test_tuned4096_variants(svc, oracle, datatype, variant):
+    nfft, hop, n_lines = 4096, 2048, 75
+    iq = oracle.synth_iq(datatype, seed=77, first_sample=5, n_samples=(n_lines - 1) * hop + nfft)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines)
+    import torch
+    d_iq = torch.from_numpy(iq).cuda()
+    svc.set_option("variant", variant)
+    try:
+        for lpw in (0, 7, 75, 200):
+            svc.set_option("lines_per_wg", lpw)
+            got = svc.compute_waterfall(d_iq, 0, nfft, datatype, n_lines, hop=hop)
+            torch.cuda.synchronize()
+            check_fp32(got.cpu().numpy(), ref, nfft)
+    finally:
+        svc.set_option("variant", 0)
+        svc.set_option("lines_per_wg", 0)
+
+
+@pytest.mark.parametrize("hop", [1024, 2048, 4096])
+@pytest.mark.parametrize("window", [sa.WIN_RECT, sa.WIN_HANN])
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le"])
+def test_tuned4096_hops_windows(svc, oracle, datatype, window, hop):
+    nfft, n_lines = 4096, 41
+    iq = oracle.synth_iq(datatype, seed=hop + window, first_sample=0, n_samples=(n_lines - 1) * hop + nfft)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window)
+    got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window)
+    check_fp32(got, ref, nfft)
+    # the generic kernel must agree too (both paths stay covered)
+    svc.set_option("force_generic", 1)
+    try:
+        got_g = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window)
+    finally:
+        svc.set_option("force_generic", 0)
+    check_fp32(got_g, ref, nfft)
