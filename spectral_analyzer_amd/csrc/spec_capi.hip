@@ -302,12 +302,10 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         if (c->opt_lines_per_wg > 0) {
             a.lines_per_wg = (uint32_t)((c->opt_lines_per_wg + lpw - 1) / lpw * lpw);
         } else if (tuned) {
-            // equal runs for the workgroups each CU holds (LDS request pins that number); short
-            // inputs still get runs of 16 lines so that overlap reuse pays
-            const uint64_t resident = (uint64_t)c->n_cu * tuned4096_wgs_per_cu((int)c->opt_variant);
-            uint64_t per = (rem + resident - 1) / resident;
-            if (per < 16) per = 16;
-            a.lines_per_wg = (uint32_t)per;
+            // Runs of 16 lines, handed out by the hardware dispatcher as workgroups
+            // retire: measured faster than one equal run per resident workgroup
+            // (tools/tune.py, profiles/): 1/16 of the input is re-read at run seams.
+            a.lines_per_wg = 16;
         } else {
             a.lines_per_wg = pick_lines_per_wg(rem, lpw);
         }

@@ -1,0 +1,92 @@
+// spec_fft_pk.h -- fp32 complex arithmetic written on 2-wide vectors so that one
+// complex add / twiddle half is ONE packed VALU instruction (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32 with op_sel / neg modifiers).
+//
+// Why: on gfx950 a VALU wave-instruction holds its SIMD for 4 cycles whether it
+// is scalar or packed (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.1
+// cycles on the scalar-source build, profiles/r01), and the 4096-point
+// spectrogram kernel is VALU-issue bound before it is HBM bound.  A complex
+// value therefore lives in an aligned VGPR pair from the load to the epilogue
+// and no lane shuffling (v_mov) is spent on packing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace specgpu {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_swap(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+
+// b + a*(-i) and b - a*(-i).  Written as an FMA with the constant (1,-1) on the
+// swapped operand: hipcc folds the swap into op_sel and keeps the constant in an
+// SGPR pair, so each is ONE v_pk_fma_f32; written as b + (a.y, -a.x) it spends a
+// v_xor and a v_mov on the per-lane negation first.
+__device__ __forceinline__ v2f pk_add_mi(v2f b, v2f a) { return __builtin_elementwise_fma(pk_swap(a), v2f{1.0f, -1.0f}, b); }
+__device__ __forceinline__ v2f pk_sub_mi(v2f b, v2f a) { return __builtin_elementwise_fma(pk_swap(a), v2f{-1.0f, 1.0f}, b); }
+
+// a * w for a run-time twiddle w = (c, d):  a*(c,c) + (a.y,a.x)*(-d,d)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
+    const v2f r = a * v2f{w.x, w.x};
+    const v2f nd = v2f{w.y, w.y} * v2f{-1.0f, 1.0f};
+    return __builtin_elementwise_fma(pk_swap(a), nd, r);
+}
+// the same with the second factor already arranged: wn = (-d, d)
+__device__ __forceinline__ v2f pk_cmul_pre(v2f a, v2f w, v2f wn) {
+    return __builtin_elementwise_fma(pk_swap(a), wn, a * v2f{w.x, w.x});
+}
+// a * (c - i s) for compile-time constants
+__device__ __forceinline__ v2f pk_cmul_const(v2f a, float c, float d) {
+    return __builtin_elementwise_fma(pk_swap(a), v2f{-d, d}, a * v2f{c, c});
+}
+
+__device__ __forceinline__ void pk_dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
+    const v2f t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, d = x1 - x3;
+    x0 = t0 + t2;
+    x2 = t0 - t2;
+    x1 = pk_add_mi(t1, d);   // t1 + (-i) d
+    x3 = pk_sub_mi(t1, d);   // t1 - (-i) d
+}
+// pk_dft4 with the third input still to be multiplied by -i (W16^4 folded in)
+__device__ __forceinline__ void pk_dft4_rot2(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
+    const v2f t0 = pk_add_mi(x0, x2), t1 = pk_sub_mi(x0, x2), t2 = x1 + x3, d = x1 - x3;
+    x0 = t0 + t2;
+    x2 = t0 - t2;
+    x1 = pk_add_mi(t1, d);
+    x3 = pk_sub_mi(t1, d);
+}
+
+// 16-point forward DFT in place, natural order out (same index algebra as
+// dft16 in spec_fft.h)
+__device__ __forceinline__ void pk_dft16(v2f (&u)[16]) {
+    constexpr float h = 0.70710678118654752440f;
+    constexpr float c1 = 0.92387953251128675613f;  // cos(pi/8)
+    constexpr float s1 = 0.38268343236508977173f;  // sin(pi/8)
+    pk_dft4(u[0], u[4], u[8], u[12]);
+    pk_dft4(u[1], u[5], u[9], u[13]);
+    pk_dft4(u[2], u[6], u[10], u[14]);
+    pk_dft4(u[3], u[7], u[11], u[15]);
+    // slot 4*k1 + n2 holds A[n2][k1]; multiply by W16^(n2*k1)
+    u[5] = pk_cmul_const(u[5], c1, -s1);                  // W16^1 = c1 - i s1
+    u[6] = pk_add_mi(u[6], u[6]) * v2f{h, h};             // W16^2 = h(1 - i)
+    u[7] = pk_cmul_const(u[7], s1, -c1);                  // W16^3 = s1 - i c1
+    u[9] = pk_add_mi(u[9], u[9]) * v2f{h, h};             // W16^2
+    /* u[10] *= W16^4 = -i : folded into the third pk_dft4 below */
+    u[11] = pk_sub_mi(u[11], u[11]) * v2f{-h, -h};        // W16^6 = -h(1 + i)
+    u[13] = pk_cmul_const(u[13], s1, -c1);                // W16^3
+    u[14] = pk_sub_mi(u[14], u[14]) * v2f{-h, -h};        // W16^6
+    u[15] = pk_cmul_const(u[15], -c1, s1);                // W16^9 = -W16^1
+    pk_dft4(u[0], u[1], u[2], u[3]);
+    pk_dft4(u[4], u[5], u[6], u[7]);
+    pk_dft4_rot2(u[8], u[9], u[10], u[11]);
+    pk_dft4(u[12], u[13], u[14], u[15]);
+    // slot 4*k1 + k2 holds X[k1 + 4*k2]: transpose to natural order (pure renaming)
+    v2f y[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) y[k1 + 4 * k2] = u[4 * k1 + k2];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k] = y[k];
+}
+
+}  // namespace specgpu

@@ -47,7 +47,6 @@ hipError_t launch_welch_f32(const WelchArgs &a, int log2n, hipStream_t s);
 
 // tuned 4096-point path (spec_k_tuned.hip); variant bit 0 = non-temporal loads/stores
 bool tuned4096_applicable(const WfArgs &a, int log2n);
-int tuned4096_wgs_per_cu(int variant);
 hipError_t launch_spectro4096(const WfArgs &a, int variant, hipStream_t s);
 
 hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);

@@ -16,6 +16,7 @@
 //   * 40 KiB of LDS per workgroup pins residency at exactly 4 workgroups per
 //     CU, which lets the host hand every resident workgroup an equal run.
 #include "spec_fft.h"
+#include "spec_fft_pk.h"
 #include "spec_internal.h"
 
 namespace specgpu {
@@ -25,49 +26,68 @@ namespace {
 constexpr int N = 4096, T = 256, E = 16;
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Raw sample formats of the tuned path.  INV_SCALE is the factor the decode
+// table divides by (SS:44-45); the FFT is linear, so for ci16 the division is
+// not applied to the samples but folded into the epilogue (one constant there
+// instead of 16 multiplies per thread and line).
 template <int KIND> struct Raw;
 template <> struct Raw<K_CF32> {
     using type = u32x2;
     static constexpr int BPS = 8;
+    static constexpr float SCALE = 1.0f;
     template <int AUX> static __device__ __forceinline__ u32x2 load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
         return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
     }
-    static __device__ __forceinline__ cx<float> dec(u32x2 u) { return {__uint_as_float(u.x), __uint_as_float(u.y)}; }
+    static __device__ __forceinline__ v2f dec(u32x2 u) { return v2f{__uint_as_float(u.x), __uint_as_float(u.y)}; }
 };
 template <> struct Raw<K_CI16> {
     using type = uint32_t;
     static constexpr int BPS = 4;
+    static constexpr float SCALE = 1.0f / 32768.0f;  // SS:44-45
     template <int AUX> static __device__ __forceinline__ uint32_t load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
         return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
     }
-    static __device__ __forceinline__ cx<float> dec(uint32_t u) {  // SS:42-45
-        return {(float)(int16_t)(u & 0xFFFFu) * (1.0f / 32768.0f), (float)((int32_t)u >> 16) * (1.0f / 32768.0f)};
+    static __device__ __forceinline__ v2f dec(uint32_t u) {
+        return v2f{(float)(int16_t)(u & 0xFFFFu), (float)((int32_t)u >> 16)};
     }
 };
 
-// 20 log10(|X| + 1e-10) for the 16 bins of a thread; one range test per thread
-__device__ __forceinline__ void db20_x16(const cx<float> (&v)[E], float (&d)[E]) {
-    float p[E], lo, hi;
+// Epilogue for the 16 bins of a thread.  `v` is the spectrum of the UNSCALED
+// samples; the true spectrum is SCALE * v.  DB: 20 log10(|X| + 1e-10) (SS:80-81);
+// else |X|^2.  One range test per thread: while every |X|^2 of the thread is
+// above 1e-4 (|X| > 1e-2), |X| + 1e-10 rounds to |X| in fp32 and the value is
+// 10 log10(p) with no square root.
+template <bool DB>
+__device__ __forceinline__ void epilogue_x16(const v2f (&v)[E], float scale, float (&d)[E]) {
+    float p[E];
 #pragma unroll
-    for (int m = 0; m < E; ++m) p[m] = v[m].x * v[m].x + v[m].y * v[m].y;
-    lo = hi = p[0];
+    for (int m = 0; m < E; ++m) {
+        const v2f s = v[m] * v[m];
+        p[m] = s.x + s.y;
+    }
+    const float s2 = scale * scale;
+    if constexpr (!DB) {
 #pragma unroll
-    for (int m = 1; m < E; ++m) { lo = fminf(lo, p[m]); hi = fmaxf(hi, p[m]); }
-    constexpr float k10 = 3.01029995663981195f;  // 10 log10(2)
-    if (lo > 1e-4f && hi < 1e37f) {  // |X| + 1e-10 == |X| in fp32: 10 log10(p), no sqrt
+        for (int m = 0; m < E; ++m) d[m] = p[m] * s2;
+    } else {
+        float lo = fminf(fminf(p[0], p[1]), p[2]), hi = fmaxf(fmaxf(p[0], p[1]), p[2]);
 #pragma unroll
-        for (int m = 0; m < E; ++m) d[m] = k10 * __log2f(p[m]);
-    } else {  // rare: a bin near the -200 dB floor or near overflow
+        for (int m = 3; m + 1 < E; m += 2) { lo = fminf(fminf(lo, p[m]), p[m + 1]); hi = fmaxf(fmaxf(hi, p[m]), p[m + 1]); }
+        lo = fminf(lo, p[E - 1]);
+        hi = fmaxf(hi, p[E - 1]);
+        constexpr float k10 = 3.01029995663981195f;  // 10 log10(2)
+        const float off = k10 * __log2f(s2);         // 20 log10(scale): 0 for cf32
+        if (lo * s2 > 1e-4f && hi < 1e37f) {
 #pragma unroll
-        for (int m = 0; m < E; ++m) d[m] = db20(v[m]);
+            for (int m = 0; m < E; ++m) d[m] = __builtin_fmaf(k10, __log2f(p[m]), off);
+        } else {  // rare: a bin near the -200 dB floor, or near overflow
+#pragma unroll
+            for (int m = 0; m < E; ++m) d[m] = db20(cx<float>{v[m].x * scale, v[m].y * scale});
+        }
     }
 }
-
-// LDS accessors (kept in one place: hipcc pairs adjacent 8-byte accesses into
-// ds_read2st64_b64 / ds_write2_b64; see DESIGN.md "LDS instruction forms")
-__device__ __forceinline__ cx<float> lds_ld(const cx<float> *base, int idx) { return base[idx]; }
-__device__ __forceinline__ void lds_st(cx<float> *base, int idx, cx<float> z) { base[idx] = z; }
 
 template <int KIND, int SH, bool HAS_WIN, bool NT, int OCC>
 __global__ __launch_bounds__(256, OCC) void spectro4096_kernel(const WfArgs a) {
@@ -75,14 +95,17 @@ __global__ __launch_bounds__(256, OCC) void spectro4096_kernel(const WfArgs a) {
     using raw_t = typename RW::type;
     constexpr int BPS = RW::BPS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cx<float> *lds = reinterpret_cast<cx<float> *>(smem);
-    cx<float> *tw2_lds = lds + N;  // [r][k] : W_256^(r k), 16 x 16
+    v2f *lds = reinterpret_cast<v2f *>(smem);
+    v4f *tw2_lds = reinterpret_cast<v4f *>(lds + N);  // [r][k] : W_256^(r k) as (c, d, -d, d), 16 x 16
     const int t = threadIdx.x, k2 = t & 15;
-    const cx<float> *__restrict__ tw = static_cast<const cx<float> *>(a.tw);
+    const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw);
 
     // twiddle set-up (once per run)
-    tw2_lds[t] = tw[(t >> 4) * (t & 15) * 16];
-    cx<float> tw3[E];
+    {
+        const v2f w0 = tw[(t >> 4) * (t & 15) * 16];
+        tw2_lds[t] = v4f{w0.x, w0.y, -w0.y, w0.y};
+    }
+    v2f tw3[E];
 #pragma unroll
     for (int r = 1; r < E; ++r) tw3[r] = tw[r * t];
     float w[E];
@@ -114,17 +137,17 @@ __global__ __launch_bounds__(256, OCC) void spectro4096_kernel(const WfArgs a) {
     for (int m = 0; m < E; ++m) raw[m] = RW::template load<AUX>(src, toff, m * T * BPS);
 
     // LDS addresses (in elements)
-    const int wr1 = 16 * t;                             // exchange 1 write: 16 t + (r ^ (t & 15))
+    int wr1 = 16 * t + k2;                              // exchange 1 write: (16 t + k2) ^ r
     const int rd1 = (t & ~15) | ((t ^ (t >> 4)) & 15);  // exchange 1 read : swz(t) + 256 m
     const int wr2 = (t >> 4) * 256 + k2;                // exchange 2 write: + 16 r
     const int rd2 = t;                                  // exchange 2 read : + 256 m
 
     for (uint32_t line = 0; line < run; ++line) {
-        cx<float> v[E];
+        v2f v[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             v[m] = RW::dec(raw[m]);
-            if constexpr (HAS_WIN) { v[m].x *= w[m]; v[m].y *= w[m]; }
+            if constexpr (HAS_WIN) v[m] *= v2f{w[m], w[m]};
         }
         // slide the window of samples and request the next line's new ones
         if constexpr (SH < E) {
@@ -136,44 +159,50 @@ __global__ __launch_bounds__(256, OCC) void spectro4096_kernel(const WfArgs a) {
         for (int m = E - SH; m < E; ++m) raw[m] = RW::template load<AUX>(src, toff, next_off + m * T * BPS);
 
         // pass 1 (P = 1): no twiddles
-        dft16(v);
+        pk_dft16(v);
         __syncthreads();  // WAR: everyone has finished reading exchange 2 of the previous line
+        asm volatile("" : "+v"(wr1));  // recompute the 16 XORed addresses per line: cheaper than 16 pinned VGPRs
 #pragma unroll
-        for (int r = 0; r < E; ++r) lds_st(lds, wr1 + (r ^ k2), v[r]);
+        for (int r = 0; r < E; ++r) lds[wr1 ^ r] = v[r];
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = lds_ld(lds, rd1 + 256 * m);
+        for (int m = 0; m < E; ++m) v[m] = lds[rd1 + 256 * m];
         // pass 2 (P = 16): W_256^(r k), k = t & 15
 #pragma unroll
-        for (int r = 1; r < E; ++r) v[r] = cmul(v[r], lds_ld(tw2_lds, r * 16 + k2));
-        dft16(v);
+        for (int r = 1; r < E; ++r) {
+            const v4f q = tw2_lds[r * 16 + k2];
+            v[r] = pk_cmul_pre(v[r], v2f{q.x, q.y}, v2f{q.z, q.w});
+        }
+        pk_dft16(v);
         __syncthreads();  // WAR on exchange 1
 #pragma unroll
-        for (int r = 0; r < E; ++r) lds_st(lds, wr2 + 16 * r, v[r]);
+        for (int r = 0; r < E; ++r) lds[wr2 + 16 * r] = v[r];
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = lds_ld(lds, rd2 + 256 * m);
+        for (int m = 0; m < E; ++m) v[m] = lds[rd2 + 256 * m];
         // pass 3 (P = 256): W_4096^(r t)
 #pragma unroll
-        for (int r = 1; r < E; ++r) v[r] = cmul(v[r], tw3[r]);
-        dft16(v);
+        for (int r = 1; r < E; ++r) {
+            // keep (c, d) only: make the value opaque so that hipcc does not hoist the
+            // derived (-d, d) pairs out of the line loop (30 more VGPRs)
+            asm volatile("" : "+v"(tw3[r]));
+            v[r] = pk_cmul(v[r], tw3[r]);
+        }
+        pk_dft16(v);
 
         // epilogue: |X| -> dB, fftshift folded into the index (SS:76-82)
         float d[E];
-        if (a.out_fmt == OUT_DB20_F32) {
-            db20_x16(v, d);
-        } else {
-#pragma unroll
-            for (int m = 0; m < E; ++m) d[m] = v[m].x * v[m].x + v[m].y * v[m].y;
-        }
+        if (a.out_fmt == OUT_DB20_F32) epilogue_x16<true>(v, RW::SCALE, d);
+        else epilogue_x16<false>(v, RW::SCALE, d);
         const int out_off = (int)(line * (uint32_t)N * 4u);
 #pragma unroll
         for (int m = 0; m < E; ++m)  // (t + m T + N/2) mod N
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, tout, out_off + ((m + E / 2) & (E - 1)) * T * 4, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, tout,
+                                                  out_off + ((m + E / 2) & (E - 1)) * T * 4, AUX);
     }
 }
 
-// LDS request: 32 KiB line + 2 KiB twiddles, padded so that exactly OCC
+// LDS request: 32 KiB line + 4 KiB twiddles, padded so that exactly OCC
 // workgroups fit the 160 KiB of a CU (the host hands out equal runs).
 constexpr size_t tuned_lds(int occ) { return occ >= 4 ? 40 * 1024 : occ == 3 ? 48 * 1024 : 80 * 1024; }
 
@@ -185,13 +214,24 @@ template <int KIND, int SH, bool HAS_WIN, bool NT, int OCC> hipError_t launch_1(
 }
 
 // variant: bit 0 = non-temporal loads/stores, bits 1-2 = occupancy choice
-// (0 -> default, 1 -> 4, 2 -> 3, 3 -> 2 workgroups per CU)
+// (0 -> default for the datatype, 1 -> 4, 2 -> 3, 3 -> 2 workgroups per CU).
+// Defaults are the largest residency the kernel reaches without spilling:
+// cf32 needs 156 VGPRs (3 per CU), ci16 120 (4 per CU).
+template <int KIND> constexpr int tuned_occ(int variant) {
+    switch ((variant >> 1) & 3) {
+    case 1: return 4;
+    case 2: return 3;
+    case 3: return 2;
+    default: return KIND == K_CI16 ? 4 : 3;
+    }
+}
+
 template <int KIND, int SH, bool HAS_WIN> hipError_t launch_v(const WfArgs &a, int variant, hipStream_t s) {
     if constexpr (SH == 8 && !HAS_WIN) {  // the headline configuration carries the experiment matrix
         const bool nt = variant & 1;
-        switch ((variant >> 1) & 3) {
-        case 1: return nt ? launch_1<KIND, SH, HAS_WIN, true, 4>(a, s) : launch_1<KIND, SH, HAS_WIN, false, 4>(a, s);
-        case 3: return nt ? launch_1<KIND, SH, HAS_WIN, true, 2>(a, s) : launch_1<KIND, SH, HAS_WIN, false, 2>(a, s);
+        switch (tuned_occ<KIND>(variant)) {
+        case 4: return nt ? launch_1<KIND, SH, HAS_WIN, true, 4>(a, s) : launch_1<KIND, SH, HAS_WIN, false, 4>(a, s);
+        case 2: return nt ? launch_1<KIND, SH, HAS_WIN, true, 2>(a, s) : launch_1<KIND, SH, HAS_WIN, false, 2>(a, s);
         default: return nt ? launch_1<KIND, SH, HAS_WIN, true, 3>(a, s) : launch_1<KIND, SH, HAS_WIN, false, 3>(a, s);
         }
     } else {
@@ -218,10 +258,6 @@ bool tuned4096_applicable(const WfArgs &a, int log2n) {
     return log2n == 12 && !a.be && (a.kind == K_CF32 || a.kind == K_CI16) &&
            (a.hop == 1024 || a.hop == 2048 || a.hop == 4096) &&
            (a.out_fmt == OUT_DB20_F32 || a.out_fmt == OUT_POW_F32);
-}
-
-int tuned4096_wgs_per_cu(int variant) {
-    switch ((variant >> 1) & 3) { case 1: return 4; case 3: return 2; default: return 3; }
 }
 
 hipError_t launch_spectro4096(const WfArgs &a, int variant, hipStream_t s) {
