@@ -1,0 +1,86 @@
+"""CPU checks of the C-ABI boundary: the shared library loads, exports every symbol that
+include/specgpu.h declares, the pure-host entry points behave like the reference's tables,
+and a context cannot be created without a GPU (there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import spectral_analyzer_amd as sa
+from spectral_analyzer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "specgpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spec_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libspecgpu.so does not export " + n
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_no_torch_in_the_abi():
+    # the boundary is plain C: the library must not link libtorch / libc10
+    import subprocess
+    out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in out and "c10" not in out
+    assert "amdhip64" in out
+
+
+def test_dtype_table_matches_reference_rules():
+    # SS:35-38 startsWith + SMH:87-91 "_le" suffix rule
+    f = sa.dtype_from_sigmf
+    assert f("cf32_le") == sa.DT_CF32_LE and f("cf32_be") == sa.DT_CF32_BE and f("cf32") == sa.DT_CF32_BE
+    assert f("ci16_le") == sa.DT_CI16_LE and f("ci16_be") == sa.DT_CI16_BE
+    assert f("cu8") == sa.DT_CU8 and f("ci8") == sa.DT_CI8 and f("cu8_le") == sa.DT_CU8
+    assert f("cf64_le") == sa.DT_CF64_LE and f("cf64_be") == sa.DT_CF64_BE
+    assert f("ri16_le") == sa.DT_UNKNOWN and f("") == sa.DT_UNKNOWN
+    # Global.java:67-79 incl. fallback 8
+    assert [sa.bytes_per_sample(d) for d in ("cf32_le", "ci16_le", "cu8", "ci8", "cf64_le", "zzz")] == [8, 4, 2, 2, 16, 8]
+
+
+def test_count_lines_is_the_range_test():
+    lib = _lib.load()
+    # MC:987: byteOffset + nfft*bps <= capacity
+    assert lib.spec_count_lines(8 * 4096, 0, sa.DT_CF32_LE, 4096, 2048) == 1
+    assert lib.spec_count_lines(8 * 4096 - 1, 0, sa.DT_CF32_LE, 4096, 2048) == 0
+    assert lib.spec_count_lines(8 << 30, 0, sa.DT_CF32_LE, 4096, 2048) == 524287
+    assert lib.spec_count_lines(4 * 1000, 4 * 300, sa.DT_CI16_LE, 256, 256) == 2
+    assert lib.spec_count_lines(100, 200, sa.DT_CU8, 16, 16) == 0
+    assert lib.spec_count_lines(100, 0, sa.DT_CU8, 16, 0) == 0
+
+
+def test_status_strings():
+    lib = _lib.load()
+    assert lib.spec_status_string(0) == b"SPEC_OK" and lib.spec_status_string(2) == b"SPEC_ERANGE"
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU backend"):
+        sa.SpectralService(0)
+    lib = _lib.load()
+    ctx = ctypes.c_void_p()
+    assert lib.spec_create(0, None, 0, ctypes.byref(ctx)) == _lib.SPEC_EDEVICE and not ctx.value
+    assert lib.spec_create(0, None, 0, None) == _lib.SPEC_EINVAL
+    # NULL-context calls do not crash
+    assert lib.spec_sync(None) == _lib.SPEC_EINVAL
+    lib.spec_destroy(None)
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()

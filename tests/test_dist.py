@@ -1,0 +1,89 @@
+"""world_size-2 (and 3) gloo tests of the time-slice sharding layer on CPU.  The per-rank
+compute is the oracle here (test infrastructure); on a GPU box the same layer is driven by
+SpectralService (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spectral_analyzer_amd import dist as sd
+
+
+def test_shard_lines_tile_the_range():
+    for total in (0, 1, 7, 524287, 4194303):
+        for world in (1, 2, 3, 8):
+            spans = [sd.shard_lines(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_shard_span_has_the_halo():
+    nfft, hop = 4096, 2048
+    a = sd.shard_span(0, 10, nfft, hop)
+    b = sd.shard_span(10, 20, nfft, hop)
+    assert a == (0, 9 * hop + nfft) and b == (10 * hop, 9 * hop + nfft)
+    assert a[0] + a[1] - b[0] == nfft - hop          # overlap between neighbouring ranks
+    assert sd.total_lines(1 << 30, 4096, 2048) == 524287 and sd.total_lines(100, 4096, 2048) == 0
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import spec_oracle as so
+        dt, nfft, hop, seed = "ci16_le", 256, 128, 21
+
+        def compute_tile(l0, l1):
+            first, n = sd.shard_span(l0, l1, nfft, hop)
+            iq = so.synth_iq(dt, seed, first, n)           # each rank generates its own span + halo
+            return torch.from_numpy(so.waterfall(iq, 0, dt, nfft, hop, l1 - l0).astype(np.float32))
+
+        full = sd.sharded_waterfall(compute_tile, total, nfft, gather_to=0)
+        local = sd.sharded_waterfall(compute_tile, total, nfft, gather_to=None)
+        l0, l1 = sd.shard_lines(total, world, rank)
+        assert local.shape == (l1 - l0, nfft)
+
+        def partial_power(s0, s1):
+            first, n = sd.shard_span(s0, s1, nfft, hop)
+            if n == 0:
+                return torch.zeros(nfft, dtype=torch.float64)
+            iq = so.synth_iq(dt, seed, first, n)
+            return torch.from_numpy(so.waterfall(iq, 0, dt, nfft, hop, s1 - s0, so.WIN_HANN, power=True).sum(axis=0))
+
+        w = so.np_window(nfft, so.WIN_HANN)
+        psd = sd.sharded_welch(partial_power, total, 1.0 / (1.0 * (w ** 2).sum()))
+        if rank == 0:
+            iq = so.synth_iq(dt, seed, 0, (total - 1) * hop + nfft)
+            ref = so.waterfall(iq, 0, dt, nfft, hop, total).astype(np.float32)
+            _, pref = so.welch_psd(iq, 0, dt, nfft, hop, total, so.WIN_HANN, so.PSD_DENSITY, 1.0)
+            q.put((bool(np.array_equal(full.numpy(), ref)),
+                   float(np.abs(psd.numpy() - pref).max() / pref.max())))
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 37), (3, 10), (2, 1)])
+def test_sharded_waterfall_and_welch_gloo(world, total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    same, psd_err = q.get(timeout=10)
+    assert same, "gathered spectrogram differs from the single-process oracle"
+    assert psd_err < 1e-12

@@ -1,0 +1,171 @@
+"""CPU tests of the oracle (no GPU): the analytic known-answer tests of SURVEY.md
+8(c) derived from SpectralService.java:40-82, the cross-check of the C
+restatement against numpy.fft / scipy.signal.welch, and the committed golden
+fixtures.  The reference publishes no vectors of its own (its only test is a
+Spring context load), so these KATs are what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import scipy.signal
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DTYPES = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "cf64_be"]
+
+
+def cf32_bytes(x, be=False):
+    v = np.empty(2 * len(x), dtype=">f4" if be else "<f4")
+    v[0::2], v[1::2] = x.real, x.imag
+    return v.view(np.uint8)
+
+
+def test_k1_all_zero_is_minus_200(oracle):
+    # SS:81: 20*log10(0 + 1e-10) = -200 exactly
+    for n in (64, 1024):
+        out = oracle.compute_magnitudes(np.zeros(8 * n, np.uint8), 0, n, "cf32_le")
+        assert np.all(out == -200.0)
+
+
+def test_k2_unknown_datatype_and_cf64_defect(oracle):
+    # SS:60-63: unknown datatype decodes to zeros; cf64 has no branch in the service (SS:35-38)
+    buf = oracle.synth_iq("cf64_le", 1, 0, 256)
+    assert np.all(oracle.compute_magnitudes(buf, 0, 256, "xyz") == -200.0)
+    assert np.all(oracle.compute_magnitudes(buf, 0, 256, "cf64_le", cf64_decode=False) == -200.0)
+    assert oracle.compute_magnitudes(buf, 0, 256, "cf64_le", cf64_decode=True).max() > 0
+
+
+def test_k3_unit_impulse_is_flat(oracle):
+    n = 256
+    x = np.zeros(n, complex); x[0] = 1
+    out = oracle.compute_magnitudes(cf32_bytes(x), 0, n, "cf32_le")
+    assert np.allclose(out, 20 * np.log10(1 + 1e-10), atol=1e-12)
+
+
+def test_k4_dc_lands_at_n_over_2(oracle):
+    n = 512
+    out = oracle.compute_magnitudes(cf32_bytes(np.ones(n, complex)), 0, n, "cf32_le")
+    assert out[n // 2] == pytest.approx(20 * np.log10(n + 1e-10), abs=1e-12)   # SS:78
+    lin = 10 ** (np.delete(out, n // 2) / 20)
+    assert lin.max() < 1e-9            # exact zeros up to the +1e-10 epsilon / round-off
+
+
+@pytest.mark.parametrize("k", [1, 37, 255, 256, 300, 511])
+def test_k5_complex_tone_bin(oracle, k):
+    n = 512
+    x = np.exp(2j * np.pi * k * np.arange(n) / n)
+    out = oracle.compute_magnitudes(cf32_bytes(x), 0, n, "cf32_le")
+    assert int(np.argmax(out)) == (k + n // 2) % n
+    assert out.max() == pytest.approx(20 * np.log10(n), abs=1e-4)   # cf32 rounding of the tone
+
+
+def test_k6_decode_table(oracle):
+    # SS:44-45 ci16 / 32768 ; SS:51-54 (b & 0xFF - 127.5) / 128 ; SS:56-59 b / 128
+    ci16 = np.array([0x8000, 0x7FFF], dtype="<u2").view(np.uint8)
+    z = oracle.np_decode(ci16, 0, 1, "ci16_le")[0]
+    assert (z.real, z.imag) == (-1.0, 32767 / 32768)
+    z = oracle.np_decode(np.array([0, 255], np.uint8), 0, 1, "cu8")[0]
+    assert (z.real, z.imag) == (-0.99609375, 0.99609375)
+    z = oracle.np_decode(np.array([0x80, 0x7F], np.uint8), 0, 1, "ci8")[0]
+    assert (z.real, z.imag) == (-1.0, 0.9921875)
+    # and the C decode agrees through a 1-point... use a 2-point FFT: X0 = a + b, X1 = a - b
+    for dt, raw in (("ci16_le", np.array([0x8000, 0x7FFF, 0x0001, 0xFFFF], dtype="<u2").view(np.uint8)),
+                    ("cu8", np.array([0, 255, 128, 127], np.uint8)), ("ci8", np.array([0x80, 0x7F, 1, 0xFF], np.uint8))):
+        x = oracle.np_decode(raw, 0, 2, dt)
+        ref = 20 * np.log10(np.abs(np.array([x[0] - x[1], x[0] + x[1]])) + 1e-10)   # fftshifted
+        assert np.allclose(oracle.compute_magnitudes(raw, 0, 2, dt), ref, atol=1e-12)
+
+
+@pytest.mark.parametrize("base", ["cf32", "ci16", "cf64"])
+def test_k7_big_and_little_endian_files_agree(oracle, base):
+    le = oracle.synth_iq(base + "_le", 5, 10, 2048)
+    be = oracle.synth_iq(base + "_be", 5, 10, 2048)
+    assert not np.array_equal(le, be)
+    a = oracle.waterfall(le, 0, base + "_le", 512, 256, 7)
+    b = oracle.waterfall(be, 0, base + "_be", 512, 256, 7)
+    assert np.array_equal(a, b)
+
+
+def test_k8_eof_lines_are_minus_150(oracle):
+    # MC:987-998: a line whose last byte passes the capacity is filled with -150.0
+    buf = oracle.synth_iq("ci16_le", 2, 0, 1000)
+    out = oracle.waterfall(buf, 0, "ci16_le", 256, 256, 5)
+    assert oracle.count_lines(buf.size, 0, "ci16_le", 256, 256) == 3
+    assert np.all(out[3:] == -150.0) and np.all(out[:3] > -150.0)
+    # start offset moves the boundary
+    assert oracle.count_lines(buf.size, 4 * 300, "ci16_le", 256, 256) == 2
+    assert oracle.count_lines(buf.size, buf.size, "ci16_le", 256, 256) == 0
+
+
+@pytest.mark.parametrize("datatype", DTYPES)
+def test_k9_parseval(oracle, datatype):
+    n, lines = 1024, 3
+    buf = oracle.synth_iq(datatype, 9, 0, n * lines)
+    p = oracle.waterfall(buf, 0, datatype, n, n, lines, power=True)
+    x = oracle.np_decode(buf, 0, n * lines, datatype).reshape(lines, n)
+    assert np.allclose(p.sum(axis=1), n * (np.abs(x) ** 2).sum(axis=1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("datatype", DTYPES)
+@pytest.mark.parametrize("nfft", [2, 64, 1024, 4096, 16384, 65536])
+def test_k10_c_restatement_matches_numpy_fft(oracle, datatype, nfft):
+    hop = max(1, nfft // 2)
+    lines = 3
+    buf = oracle.synth_iq(datatype, nfft, 7, (lines - 1) * hop + nfft)
+    for window in (oracle.WIN_RECT, oracle.WIN_HANN):
+        a = oracle.waterfall(buf, 0, datatype, nfft, hop, lines, window, power=True)
+        X = oracle.np_spectrum(buf, 0, datatype, nfft, hop, lines, window)
+        b = np.fft.fftshift(np.abs(X) ** 2, axes=1)
+        assert np.abs(a - b).max() <= 1e-12 * b.max()
+
+
+def test_fft_rejects_non_power_of_two(oracle):
+    with pytest.raises(ValueError):
+        oracle.fft_forward(np.zeros(12, complex))
+    with pytest.raises(ValueError):
+        oracle.compute_magnitudes(np.zeros(8 * 100, np.uint8), 0, 100, "cf32_le")
+    with pytest.raises(IndexError):
+        oracle.compute_magnitudes(np.zeros(8 * 64, np.uint8), 8, 64, "cf32_le")
+
+
+def test_bytes_per_sample_table(oracle):
+    # Global.java:67-79 incl. the fallback
+    assert [oracle.bytes_per_sample(d) for d in ("cf32_le", "ci16_be", "cu8", "ci8", "cf64_le", "weird")] == [8, 4, 2, 2, 16, 8]
+
+
+def test_display_conversion(oracle):
+    # MC:1273-1274
+    assert oracle.display_conversion(1e6, 1024) == pytest.approx(10 * np.log10(1e6 / 1024) + 20 * np.log10(1024))
+
+
+@pytest.mark.parametrize("scaling", ["density", "spectrum"])
+@pytest.mark.parametrize("window", ["hann", "boxcar"])
+def test_welch_matches_scipy(oracle, scaling, window):
+    nfft, hop, n_seg, fs = 1024, 256, 9, 2.5e6
+    buf = oracle.synth_iq("cf32_le", 4, 0, (n_seg - 1) * hop + nfft)
+    x = oracle.np_decode(buf, 0, (n_seg - 1) * hop + nfft, "cf32_le")
+    f_ref, p_ref = scipy.signal.welch(x, fs, window=window, nperseg=nfft, noverlap=nfft - hop, nfft=nfft,
+                                      detrend=False, return_onesided=False, scaling=scaling)
+    f, p = oracle.welch_psd(buf, 0, "cf32_le", nfft, hop, n_seg,
+                            oracle.WIN_HANN if window == "hann" else oracle.WIN_RECT,
+                            oracle.PSD_DENSITY if scaling == "density" else oracle.PSD_SPECTRUM, fs)
+    assert np.allclose(f, np.fft.fftshift(f_ref))
+    assert np.abs(p - np.fft.fftshift(p_ref)).max() <= 1e-12 * p_ref.max()
+
+
+def test_golden_fixtures(oracle):
+    """tests/golden/*.npz were written by tests/golden/make_golden.py from the C oracle after
+    the numpy cross-check; they freeze the expected lines so a later oracle edit cannot drift."""
+    files = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert files, "no golden fixtures committed"
+    for f in files:
+        g = np.load(os.path.join(GOLDEN, f))
+        dt, nfft, hop, window = str(g["datatype"]), int(g["nfft"]), int(g["hop"]), int(g["window"])
+        out = oracle.waterfall(g["iq"], 0, dt, nfft, hop, g["db"].shape[0], window)
+        lin, lin_ref = 10 ** (out / 20), 10 ** (g["db"].astype(np.float64) / 20)
+        assert np.abs(lin - lin_ref).max() <= 1e-9 * lin_ref.max(), f
+
+
+def test_synth_is_counter_based(oracle):
+    a = oracle.synth_iq("ci16_le", 77, 0, 4096)
+    b = oracle.synth_iq("ci16_le", 77, 1000, 1000)
+    assert np.array_equal(a[4000:8000], b)      # any shard regenerates its own span
