@@ -82,6 +82,9 @@ typedef enum {
 #define SPEC_FLAG_REF_CF64_ZERO 0x1u /* reproduce the reference defect: computeMagnitudes has
                                         no cf64 branch, so cf64 input yields -200 dB (SS:35-63) */
 
+#define SPEC_FLAG_NULL_STREAM 0x2u   /* with hip_stream == NULL: launch on the device's default (null)
+                                        stream instead of creating a private one */
+
 /* ---- context ------------------------------------------------------------ */
 
 /* Bind a context to HIP device `device` (>= 0).  `hip_stream` is a hipStream_t

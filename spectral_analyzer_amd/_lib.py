@@ -22,6 +22,7 @@ WIN_RECT, WIN_HANN = 0, 1
 OUT_DB20_F32, OUT_POW_F32, OUT_DB20_F64, OUT_POW_F64 = range(4)
 PSD_DENSITY, PSD_SPECTRUM = 0, 1
 FLAG_REF_CF64_ZERO = 0x1
+FLAG_NULL_STREAM = 0x2
 
 # every symbol include/specgpu.h declares, with its ctypes signature
 _u64, _u32, _i32, _vp, _cp, _dbl = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_char_p, C.c_double

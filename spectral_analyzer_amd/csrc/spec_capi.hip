@@ -144,6 +144,8 @@ spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx *
     if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, SPEC_EDEVICE, "hipSetDevice(%d) failed", device); }
     if (hip_stream) {
         c->stream = static_cast<hipStream_t>(hip_stream);
+    } else if (flags & SPEC_FLAG_NULL_STREAM) {
+        c->stream = nullptr;  // the default stream: ordered with everything else the process queues on it
     } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
             delete c;
@@ -279,8 +281,10 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                              uint64_t n_lines, spec_window window, spec_out_fmt fmt, void *d_out) {
     if (n_lines == 0) return SPEC_OK;
     const bool f64 = fmt >= SPEC_OUT_DB20_F64 || dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
-    if (!plan_supported(log2n, f64))
-        return fail(c, SPEC_EUNSUPPORTED, "nfft = 2^%d is not supported in %s yet", log2n, f64 ? "fp64" : "fp32");
+    int l1 = 0, l2 = 0;
+    const bool large = !plan_supported(log2n, f64) && large_split(log2n, f64, &l1, &l2);
+    if (!plan_supported(log2n, f64) && !large)
+        return fail(c, SPEC_EUNSUPPORTED, "nfft = 2^%d is not supported in %s", log2n, f64 ? "fp64" : "fp32");
     WfArgs a{};
     a.iq = d_first;
     a.hop = hop;
@@ -292,8 +296,27 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     if (st != SPEC_OK) return st;
     st = get_window(c, log2n, f64, window, &a.win, nullptr, nullptr);
     if (st != SPEC_OK) return st;
-    const int lpw = plan_lpw(log2n);
     const uint64_t out_esz = fmt >= SPEC_OUT_DB20_F64 ? 8 : 4, nfft = 1ull << log2n;
+    if (large) {
+        // four-step path: chunks of lines whose scratch stays inside the Infinity Cache
+        const void *tw1 = nullptr, *tw2 = nullptr;
+        if ((st = get_twiddles(c, l1, f64, &tw1)) != SPEC_OK) return st;
+        if ((st = get_twiddles(c, l2, f64, &tw2)) != SPEC_OK) return st;
+        const size_t per_line = large_scratch_bytes_per_line(log2n, f64);
+        uint64_t chunk = (192ull << 20) / per_line;
+        if (chunk == 0) chunk = 1;
+        if (chunk > n_lines) chunk = n_lines;
+        if ((st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)chunk * per_line)) != SPEC_OK) return st;
+        for (uint64_t done = 0; done < n_lines; done += chunk) {
+            a.n_lines = n_lines - done < chunk ? n_lines - done : chunk;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_spectro_large(a, log2n, f64, tw1, tw2, c->scratch, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N launch: %s", hipGetErrorString(e));
+        }
+        return SPEC_OK;
+    }
+    const int lpw = plan_lpw(log2n);
     const bool tuned = !f64 && !c->opt_force_generic && tuned4096_applicable(a, log2n);
     // one launch covers at most 2^31 - 1 workgroups; split very long recordings
     uint64_t done = 0;
@@ -351,8 +374,12 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
     uint64_t n_valid = spec_count_lines(n_bytes, start_byte, dt, nfft, hop);
     if (n_valid > n_lines) n_valid = n_lines;
     const bool f64 = out_fmt >= SPEC_OUT_DB20_F64 || dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
-    if (n_valid && !plan_supported(log2n, f64))
-        return fail(c, SPEC_EUNSUPPORTED, "nfft = %u is not supported in %s yet", nfft, f64 ? "fp64" : "fp32");
+    {
+        int l1 = 0, l2 = 0;
+        if (n_valid && !plan_supported(log2n, f64) && !large_split(log2n, f64, &l1, &l2))
+            return fail(c, SPEC_EUNSUPPORTED, "nfft = %u is not supported in %s (64 ... 65536)", nfft,
+                        f64 ? "fp64" : "fp32");
+    }
 
     if (iq_on_device && out_on_device) {
         const uint8_t *first = static_cast<const uint8_t *>(iq) + start_byte;

@@ -205,6 +205,23 @@ __device__ __forceinline__ void fft_line(cx<R> (&v)[Plan<LOG2N>::E], int t, cx<R
     }
 }
 
+// Same transform with a change of thread roles at the first exchange: pass 0 is
+// done by butterfly index t0 on line buffer lds0, everything after the first
+// LDS round trip by (t1, lds1).  Used by the large-N kernels, whose global loads
+// want one lane order (lines fastest) and whose stores want the other.
+template <typename R, int LOG2N>
+__device__ __forceinline__ void fft_line_remap(cx<R> (&v)[Plan<LOG2N>::E], int t0, cx<R> *lds0, int t1,
+                                               cx<R> *lds1, const cx<R> *__restrict__ tw) {
+    using PL = Plan<LOG2N>;
+    static_assert(PL::NPASS >= 2, "needs an exchange to remap at");
+    fft_pass_regs<R, LOG2N, 0>(v, t0, tw);
+    fft_pass_store<R, LOG2N, 0>(v, t0, lds0);
+    __syncthreads();
+    fft_pass_load<R, LOG2N>(v, t1, lds1);
+    __syncthreads();
+    fft_line<R, LOG2N, 1>(v, t1, lds1, tw);
+}
+
 // ---------------------------------------------------------------------------
 // sample decode (SpectralService.java:40-65, ExtractDownConvertService.java:79-81)
 // ---------------------------------------------------------------------------

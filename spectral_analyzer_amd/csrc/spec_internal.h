@@ -49,6 +49,13 @@ hipError_t launch_welch_f32(const WelchArgs &a, int log2n, hipStream_t s);
 bool tuned4096_applicable(const WfArgs &a, int log2n);
 hipError_t launch_spectro4096(const WfArgs &a, int variant, hipStream_t s);
 
+// large-N four-step path (spec_k_large.hip): w.tw is the W_N table, tw1/tw2 the
+// W_N1 / W_N2 tables of the split, scratch holds n_lines * N complex values
+bool large_split(int log2n, bool f64, int *l1, int *l2);
+size_t large_scratch_bytes_per_line(int log2n, bool f64);
+hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2,
+                                void *scratch, hipStream_t s);
+
 hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);
 hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs,
                                  uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);

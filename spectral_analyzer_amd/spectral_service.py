@@ -58,9 +58,15 @@ class SpectralService:
     """GPU-backed drop-in for the reference ``SpectralService`` singleton."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None, ref_cf64_zero: bool = False):
+        """``stream`` is a hipStream_t handle (e.g. ``torch.cuda.Stream().cuda_stream``);
+        None means the device's default stream, so device-resident results are
+        ordered with PyTorch work on its default stream.  Device-pointer calls
+        are asynchronous on that stream."""
         self._lib = L.load()
         self._ctx = C.c_void_p()
         flags = L.FLAG_REF_CF64_ZERO if ref_cf64_zero else 0
+        if not stream:
+            flags |= L.FLAG_NULL_STREAM
         st = self._lib.spec_create(int(device), C.c_void_p(stream) if stream else None, flags,
                                    C.byref(self._ctx))
         if st != L.SPEC_OK:

@@ -1,0 +1,284 @@
+"""GPU tests of the drop-in boundary: the exact computeMagnitudes call, its error
+behaviour, the batched line loop with EOF fill, fp64 strict parity, Welch PSD, device-
+resident buffers, the committed golden fixtures, and full-size property checks."""
+import os
+
+import numpy as np
+import pytest
+
+import spectral_analyzer_amd as sa
+from test_gpu_parity import check_fp32, check_fp64
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DTYPES = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "cf64_be"]
+
+
+# ---- SpectralService.computeMagnitudes (SS:33-85), fp64 pipeline -----------------------
+@pytest.mark.parametrize("datatype", DTYPES)
+@pytest.mark.parametrize("nfft", [64, 1024, 8192])
+def test_compute_magnitudes_fp64_parity(svc, oracle, datatype, nfft):
+    iq = oracle.synth_iq(datatype, 31, 17, nfft + 50)
+    start = 3 * oracle.bytes_per_sample(datatype)
+    ref = oracle.compute_magnitudes(iq, start, nfft, datatype, cf64_decode=True)
+    got = svc.compute_magnitudes(iq, start, nfft, datatype)
+    assert got.dtype == np.float64 and got.shape == (nfft,)
+    check_fp64(got[None, :], ref[None, :])
+
+
+def test_compute_magnitudes_known_answers(svc):
+    n = 256
+    assert np.all(svc.compute_magnitudes(np.zeros(8 * n, np.uint8), 0, n, "cf32_le") == -200.0)       # K1
+    assert np.all(svc.compute_magnitudes(np.ones(8 * n, np.uint8), 0, n, "what") == -200.0)           # K2
+    x = np.zeros(2 * n, "<f4"); x[0] = 1.0
+    assert np.allclose(svc.compute_magnitudes(x, 0, n, "cf32_le"), 20 * np.log10(1 + 1e-10), atol=1e-9)  # K3
+    dc = np.zeros(2 * n, "<f4"); dc[0::2] = 1.0
+    out = svc.compute_magnitudes(dc, 0, n, "cf32_le")
+    assert out[n // 2] == pytest.approx(20 * np.log10(n), abs=1e-9) and np.delete(out, n // 2).max() < -150   # K4
+    k = 37
+    tone = np.exp(2j * np.pi * k * np.arange(n) / n)
+    t = np.empty(2 * n, "<f8"); t[0::2], t[1::2] = tone.real, tone.imag
+    out = svc.compute_magnitudes(t, 0, n, "cf64_le")
+    assert int(np.argmax(out)) == (k + n // 2) % n and out.max() == pytest.approx(20 * np.log10(n), abs=1e-9)  # K5
+
+
+def test_compute_magnitudes_byte_order_is_the_buffers(svc, oracle):
+    le = oracle.synth_iq("ci16_le", 8, 0, 512)
+    be = oracle.synth_iq("ci16_be", 8, 0, 512)
+    a = svc.compute_magnitudes(le, 0, 512, "ci16_le")
+    b = svc.compute_magnitudes(be, 0, 512, "ci16_be")
+    c = svc.compute_magnitudes(be, 0, 512, "ci16", big_endian=True)     # startsWith match, explicit order
+    assert np.array_equal(a, b) and np.array_equal(a, c)                 # K7
+
+
+def test_compute_magnitudes_errors(svc):
+    buf = np.zeros(8 * 64, np.uint8)
+    with pytest.raises(ValueError):            # commons-math3: not a power of two
+        svc.compute_magnitudes(buf, 0, 48, "cf32_le")
+    with pytest.raises(ValueError):
+        svc.compute_magnitudes(buf, 0, 0, "cf32_le")
+    with pytest.raises(IndexError):            # ByteBuffer getters: IndexOutOfBoundsException
+        svc.compute_magnitudes(buf, 8, 64, "cf32_le")
+    with pytest.raises(IndexError):
+        svc.compute_magnitudes(buf, -8, 64, "cf32_le")
+    # an unknown datatype never touches the buffer (SS:60-63), so no range error
+    assert np.all(svc.compute_magnitudes(buf, 10 ** 6, 64, "nope") == -200.0)
+
+
+def test_cf64_reference_defect_flag(oracle):
+    iq = oracle.synth_iq("cf64_le", 1, 0, 256)
+    with sa.SpectralService(0, ref_cf64_zero=True) as s:
+        assert np.all(s.compute_magnitudes(iq, 0, 256, "cf64_le") == -200.0)     # SS:35-63 has no cf64 branch
+        assert np.all(s.compute_waterfall(iq, 0, 256, "cf64_le", 1) == -200.0)
+    with sa.SpectralService(0) as s:
+        assert s.compute_magnitudes(iq, 0, 256, "cf64_le").max() > 0            # EDC:79-81 decode
+
+
+# ---- the line loop (MC:980-999) ----------------------------------------------------------
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_be", "cu8"])
+def test_eof_fill_and_start_byte(svc, oracle, datatype):
+    nfft = 256
+    bps = oracle.bytes_per_sample(datatype)
+    iq = oracle.synth_iq(datatype, 6, 0, 1000)
+    for start in (0, 300 * bps):
+        ref = oracle.waterfall(iq, start, datatype, nfft, nfft, 6)      # reference hop == nfft
+        got = svc.compute_waterfall(iq, start, nfft, datatype, 6)       # hop defaults to nfft
+        valid = oracle.count_lines(iq.size, start, datatype, nfft, nfft)
+        assert svc.count_lines(iq.size, start, datatype, nfft, nfft) == valid < 6
+        assert np.all(got[valid:] == -150.0)                             # MC:994-998
+        check_fp32(got[:valid], ref[:valid], nfft)
+    got = svc.compute_waterfall(iq, 0, nfft, datatype, 4, eof_fill=-99.5)
+    assert np.all(got[3:] == -99.5)
+    assert svc.compute_waterfall(iq, 0, nfft, datatype, 0).shape == (0, nfft)
+    assert np.all(svc.compute_waterfall(iq, iq.size + 10, nfft, datatype, 2) == -150.0)
+
+
+@pytest.mark.parametrize("hop", [1, 100, 256, 300, 1024])
+def test_any_hop(svc, oracle, hop):
+    nfft, n_lines, dt = 256, 11, "ci8"
+    iq = oracle.synth_iq(dt, hop, 0, (n_lines - 1) * hop + nfft)
+    check_fp32(svc.compute_waterfall(iq, 0, nfft, dt, n_lines, hop=hop),
+               oracle.waterfall(iq, 0, dt, nfft, hop, n_lines), nfft)
+
+
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le", "cf64_be"])
+@pytest.mark.parametrize("nfft", [128, 4096, 8192])
+def test_fp64_outputs_strict(svc, oracle, datatype, nfft):
+    hop, n_lines = nfft // 4, 5
+    iq = oracle.synth_iq(datatype, 12, 0, (n_lines - 1) * hop + nfft)
+    for window in (sa.WIN_RECT, sa.WIN_HANN):
+        ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window)
+        got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_DB20_F64)
+        assert got.dtype == np.float64
+        check_fp64(got, ref)
+        p_ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window, power=True)
+        p = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_POW_F64)
+        assert np.abs(p - p_ref).max() <= 1e-12 * p_ref.max()
+
+
+@pytest.mark.parametrize("nfft", [512, 4096])
+def test_power_output_and_parseval(svc, oracle, nfft):
+    dt, n_lines = "ci16_le", 20
+    iq = oracle.synth_iq(dt, 3, 0, n_lines * nfft)
+    p = svc.compute_waterfall(iq, 0, nfft, dt, n_lines, out_fmt=sa.OUT_POW_F32).astype(np.float64)
+    p_ref = oracle.waterfall(iq, 0, dt, nfft, nfft, n_lines, power=True)
+    assert np.abs(p - p_ref).max() <= 2e-6 * p_ref.max()
+    x = oracle.np_decode(iq, 0, n_lines * nfft, dt).reshape(n_lines, nfft)
+    assert np.allclose(p.sum(axis=1), nfft * (np.abs(x) ** 2).sum(axis=1), rtol=2e-6)      # K9
+
+
+def test_argument_errors(svc, oracle):
+    iq = oracle.synth_iq("cf32_le", 1, 0, 4096)
+    with pytest.raises(ValueError):
+        svc.compute_waterfall(iq, 0, 1000, "cf32_le", 1)
+    with pytest.raises(ValueError):
+        svc.compute_waterfall(iq, 0, 1024, "cf32_le", 1, hop=0)
+    with pytest.raises(ValueError):
+        svc.compute_waterfall(iq, 0, 1024, "cf32_le", 1, window=7)
+    with pytest.raises(ValueError):
+        svc.set_option("no_such_knob", 1)
+
+
+# ---- device-resident buffers (the bench path) -------------------------------------------------
+def test_device_buffers_and_alignment(svc, oracle):
+    import torch
+    dt, nfft, hop, n_lines = "ci16_le", 1024, 512, 9
+    iq = oracle.synth_iq(dt, 2, 0, (n_lines - 1) * hop + nfft + 3)
+    d = torch.from_numpy(iq).cuda()
+    ref = oracle.waterfall(iq, 4, dt, nfft, hop, n_lines + 1)
+    got = svc.compute_waterfall(d, 4, nfft, dt, n_lines + 1, hop=hop)
+    assert got.is_cuda and got.shape == (n_lines + 1, nfft)
+    torch.cuda.synchronize()
+    g = got.cpu().numpy()
+    assert np.all(g[-1] == -150.0)
+    check_fp32(g[:-1], ref[:-1], nfft)
+    with pytest.raises(ValueError, match="aligned"):
+        svc.compute_waterfall(d, 1, nfft, dt, 1, hop=hop)      # odd byte offset for 2-byte components
+    with pytest.raises(ValueError):
+        svc.compute_waterfall(d.cpu(), 0, nfft, dt, 1)          # torch CPU tensor is not a device buffer
+
+
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le"])
+def test_device_synth_matches_cpu_generator(svc, oracle, datatype):
+    n, first = 5000, 123456789
+    dev = svc.synth_iq(datatype, 0x5EC7A11A, first, n).cpu().numpy()
+    host = oracle.synth_iq(datatype, 0x5EC7A11A, first, n)
+    a = oracle.np_decode(dev, 0, n, datatype)
+    b = oracle.np_decode(host, 0, n, datatype)
+    tol = {"cu8": 1 / 128 + 1e-6, "ci8": 1 / 128 + 1e-6}.get(datatype, 1 / 32768 + 2e-6)   # one quantisation step
+    assert np.abs(a - b).max() <= tol
+
+
+# ---- Welch PSD (ADC:303-313 call site) ----------------------------------------------------------
+@pytest.mark.parametrize("nfft,hop,n_seg", [(1024, 512, 7), (8192, 4096, 5), (16384, 4096, 16), (256, 64, 33)])
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le", "cu8"])
+def test_welch_matches_oracle(svc, oracle, datatype, nfft, hop, n_seg):
+    fs = 2.4e6
+    iq = oracle.synth_iq(datatype, 5, 0, (n_seg - 1) * hop + nfft)
+    for window, scaling in ((sa.WIN_HANN, sa.PSD_DENSITY), (sa.WIN_RECT, sa.PSD_SPECTRUM)):
+        f_ref, p_ref = oracle.welch_psd(iq, 0, datatype, nfft, hop, n_seg, window, scaling, fs)
+        f, p = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=window, scaling=scaling)
+        assert np.array_equal(f, f_ref) and p.shape == (1, nfft)
+        assert np.abs(p[0] - p_ref).max() <= 5e-6 * p_ref.max()
+        _, pdb = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=window, scaling=scaling, db=True)
+        _, pdb_ref = oracle.welch_psd(iq, 0, datatype, nfft, hop, n_seg, window, scaling, fs, db=True)
+        strong = p_ref >= 1e-3 * p_ref.max()
+        assert np.abs(pdb[0] - pdb_ref)[strong].max() <= 2e-3
+
+
+def test_welch_batch_and_defaults(svc, oracle):
+    import torch
+    dt, nfft, hop, n_seg, n_psd, fs = "cf32_le", 1024, 512, 6, 5, 1e6
+    per = (n_seg - 1) * hop + nfft
+    iq = oracle.synth_iq(dt, 13, 0, per * n_psd)
+    f, p = svc.welch_psd(torch.from_numpy(iq).cuda(), 0, dt, fs, nfft=nfft, hop=hop, n_seg=n_seg,
+                         n_psd=n_psd, psd_stride_bytes=per * 8)
+    torch.cuda.synchronize()
+    p = p.cpu().numpy()
+    for b in range(n_psd):
+        _, ref = oracle.welch_psd(iq, b * per * 8, dt, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY, fs)
+        assert np.abs(p[b] - ref).max() <= 5e-6 * ref.max()
+    # defaults: hop = nfft/2, every whole segment (the short-signal rule of ADC:303-313 is the caller's)
+    _, p_all = svc.welch_psd(iq, 0, dt, fs, nfft=nfft)
+    n_all = oracle.count_lines(iq.size, 0, dt, nfft, nfft // 2)
+    _, ref = oracle.welch_psd(iq, 0, dt, nfft, nfft // 2, n_all, oracle.WIN_HANN, oracle.PSD_DENSITY, fs)
+    assert np.abs(p_all[0] - ref).max() <= 5e-6 * ref.max()
+    with pytest.raises(IndexError):
+        svc.welch_psd(iq, 0, dt, fs, nfft=nfft, hop=hop, n_seg=10 ** 6)
+
+
+# ---- committed golden vectors --------------------------------------------------------------------
+def test_golden_fixtures_on_gpu(svc):
+    files = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert files
+    for f in files:
+        g = np.load(os.path.join(GOLDEN, f))
+        dt, nfft, hop, window = str(g["datatype"]), int(g["nfft"]), int(g["hop"]), int(g["window"])
+        ref = g["db"]
+        got = svc.compute_waterfall(g["iq"], 0, nfft, dt, ref.shape[0], hop=hop, window=window)
+        assert np.all(got[-1] == -150.0), f
+        check_fp32(got[:-1], ref[:-1], nfft)
+        got64 = svc.compute_waterfall(g["iq"], 0, nfft, dt, ref.shape[0], hop=hop, window=window, out_fmt=sa.OUT_DB20_F64)
+        check_fp64(got64[:-1], ref[:-1])
+
+
+# ---- full-size property checks (BASELINE configs 2 and 3 sizes per GPU) -------------------------
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le"])
+def test_full_size_properties(svc, oracle, datatype):
+    import torch
+    nfft, hop, S = 4096, 2048, 1 << 30
+    bps = sa.bytes_per_sample(datatype)
+    n_lines = (S - nfft) // hop + 1
+    iq = svc.synth_iq(datatype, 0x5EC7A11A, 0, S)
+    out = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + 2, hop=hop)
+    torch.cuda.synchronize()
+    assert out.shape == (n_lines + 2, nfft)
+    assert bool((out[n_lines:] == -150.0).all())                       # EOF lines
+    assert bool(torch.isfinite(out).all())
+    # the 0.123 cycles/sample tone peaks at the same bin of every line
+    peak = out[:n_lines].argmax(dim=1)
+    k = int(round(0.123 * nfft)) + nfft // 2
+    assert bool(((peak - k).abs() <= 1).all())
+    # sampled lines against the oracle on the very bytes the GPU read
+    rng = np.random.default_rng(1)
+    for ln in [0, 1, n_lines - 1] + [int(x) for x in rng.integers(0, n_lines, 5)]:
+        raw = iq[ln * hop * bps:(ln * hop + nfft) * bps].cpu().numpy()
+        ref = oracle.waterfall(raw, 0, datatype, nfft, hop, 1)
+        check_fp32(out[ln].cpu().numpy()[None, :], ref, nfft)
+    # Parseval on a block of lines (power output of the same path)
+    blk = 64
+    p = svc.compute_waterfall(iq, 0, nfft, datatype, blk, hop=hop, out_fmt=sa.OUT_POW_F32)
+    torch.cuda.synchronize()
+    x = oracle.np_decode(iq[:((blk - 1) * hop + nfft) * bps].cpu().numpy(), 0, (blk - 1) * hop + nfft, datatype)
+    for ln in (0, 17, blk - 1):
+        e = (np.abs(x[ln * hop:ln * hop + nfft]) ** 2).sum() * nfft
+        assert float(p[ln].double().sum()) == pytest.approx(e, rel=5e-6)
+    del out, iq, p
+    torch.cuda.empty_cache()
+
+
+# ---- lines longer than the LDS: four-step path (spec_k_large.hip) ----------------------------------
+@pytest.mark.parametrize("datatype,nfft,fmt", [("cf32_le", 32768, "f32"), ("ci16_le", 65536, "f32"),
+                                               ("cf64_le", 65536, "f64"), ("cf64_be", 16384, "f64"),
+                                               ("cu8", 32768, "f64"), ("cf32_le", 65536, "f64")])
+def test_large_nfft(svc, oracle, datatype, nfft, fmt):
+    hop, n_lines = nfft // 2, 5
+    iq = oracle.synth_iq(datatype, 21, 3, (n_lines - 1) * hop + nfft)
+    for window in (sa.WIN_RECT, sa.WIN_HANN):
+        ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines + 1, window)
+        if fmt == "f64":
+            got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + 1, hop=hop, window=window, out_fmt=sa.OUT_DB20_F64)
+            check_fp64(got[:-1], ref[:-1])
+        else:
+            got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + 1, hop=hop, window=window)
+            check_fp32(got[:-1], ref[:-1], nfft)
+        assert np.all(got[-1] == -150.0)
+
+
+def test_compute_magnitudes_at_ui_maximum(svc, oracle):
+    # main-scene.fxml:129-132: the NFFT slider tops out at 2^16
+    iq = oracle.synth_iq("ci16_le", 2, 0, 65536)
+    got = svc.compute_magnitudes(iq, 0, 65536, "ci16_le")
+    check_fp64(got[None, :], oracle.compute_magnitudes(iq, 0, 65536, "ci16_le")[None, :])
+    with pytest.raises(NotImplementedError):
+        svc.compute_magnitudes(np.zeros(8 << 17, np.uint8), 0, 1 << 17, "cf32_le")
