@@ -44,8 +44,8 @@ SEED = 0x5EC7A11A
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)  # the clock needs ~10 launches to settle
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--log2-samples", type=int, default=None, help="override samples per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

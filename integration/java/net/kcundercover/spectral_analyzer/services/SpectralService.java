@@ -1,0 +1,94 @@
+package net.kcundercover.spectral_analyzer.services;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.nio.MappedByteBuffer;
+import org.springframework.stereotype.Service;
+
+/**
+ * GPU-backed replacement for the reference service of the same name: same
+ * package, class and {@code computeMagnitudes} signature, so MainController's
+ * {@code @Autowired} field keeps working unchanged.  All numeric work is done by
+ * libspecgpu.so (HIP kernels for MI355X) through the JNI shim
+ * integration/jni/specgpu_jni.c; this class holds no FFT code.
+ *
+ * Added on top of the reference API: {@link #computeWaterfall} (the whole slice
+ * loop of MainController.updateDisplay in one call) and {@link #welchPsd}
+ * (the PSD dialog's Welch estimate).
+ */
+@Service
+public class SpectralService implements AutoCloseable {
+
+    /** window ids of include/specgpu.h */
+    public static final int WINDOW_RECT = 0, WINDOW_HANN = 1;
+    /** PSD scalings of include/specgpu.h */
+    public static final int PSD_DENSITY = 0, PSD_SPECTRUM = 1;
+
+    static {
+        System.loadLibrary("specgpu_jni");
+    }
+
+    private final long handle;
+
+    /** Binds GPU 0 (override with -Dspecgpu.device=N). */
+    public SpectralService() {
+        this.handle = nativeCreate(Integer.getInteger("specgpu.device", 0), 0);
+    }
+
+    /**
+     * One spectrogram line, exactly as the reference returns it:
+     * {@code out[(i + nfft/2) % nfft] = 20 log10(|X_i| + 1e-10)}.
+     *
+     * @throws IllegalArgumentException  nfft is not a power of two
+     * @throws IndexOutOfBoundsException the slice leaves the buffer
+     */
+    public double[] computeMagnitudes(MappedByteBuffer buffer, int startByte, int nfft, String datatype) {
+        double[] line = new double[Math.max(nfft, 0)];
+        nativeComputeMagnitudes(handle, buffer, startByte, nfft, datatype,
+                buffer.order() == ByteOrder.BIG_ENDIAN, line);
+        return line;
+    }
+
+    /**
+     * All {@code nLines} lines of a redraw in one device call; line t starts
+     * {@code t * hop} samples after {@code startByte}.  Lines that run past the end of
+     * the buffer come back as -150.0, as the caller's loop used to fill them.
+     * Returned row-major, {@code nLines x nfft}.
+     */
+    public float[] computeWaterfall(ByteBuffer buffer, long startByte, int nfft, int hop, int nLines,
+                                    String datatype, int window) {
+        float[] tile = new float[Math.multiplyExact(nLines, nfft)];
+        nativeWaterfall(handle, buffer, startByte, nativeDtype(datatype), nfft, hop, nLines, window, -150.0, tile);
+        return tile;
+    }
+
+    /** Welch PSD of the samples from {@code startByte}; returns {frequency axis, psd}. */
+    public double[][] welchPsd(ByteBuffer buffer, long startByte, String datatype, double sampleRate,
+                               int nfft, int hop, int segments, int window, int scaling, boolean decibel) {
+        double[] freq = new double[nfft];
+        float[] psd = new float[nfft];
+        nativeWelch(handle, buffer, startByte, nativeDtype(datatype), nfft, hop, segments, window, scaling,
+                sampleRate, decibel, freq, psd);
+        double[] wide = new double[nfft];
+        for (int i = 0; i < nfft; i++) {
+            wide[i] = psd[i];
+        }
+        return new double[][] {freq, wide};
+    }
+
+    @Override
+    public void close() {
+        nativeDestroy(handle);
+    }
+
+    private static native long nativeCreate(int device, int flags);
+    private static native void nativeDestroy(long handle);
+    private static native void nativeComputeMagnitudes(long handle, ByteBuffer buffer, int startByte, int nfft,
+                                                       String datatype, boolean bigEndian, double[] out);
+    private static native void nativeWaterfall(long handle, ByteBuffer buffer, long startByte, int dtype, int nfft,
+                                               int hop, long nLines, int window, double eofFill, float[] out);
+    private static native void nativeWelch(long handle, ByteBuffer buffer, long startByte, int dtype, int nfft,
+                                           int hop, int segments, int window, int scaling, double sampleRate,
+                                           boolean decibel, double[] freq, float[] psd);
+    private static native int nativeDtype(String datatype);
+}

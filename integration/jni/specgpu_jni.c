@@ -1,0 +1,112 @@
+/*
+ * specgpu_jni.c -- thin JNI shim between the Java host and the C ABI of
+ * include/specgpu.h.  One native method per C entry point; no arithmetic here.
+ *
+ * Java class bound: net.kcundercover.spectral_analyzer.services.SpectralService
+ * (the '_' of "spectral_analyzer" is mangled as "_1").  The MappedByteBuffer the
+ * reference hands to computeMagnitudes (SpectralService.java:33,
+ * SigMfHelper.java:84) is a direct buffer, so GetDirectBufferAddress gives the
+ * mapped bytes without a copy.
+ *
+ * Build (needs a JDK for jni.h; none exists in the authoring container, so this
+ * file is compiled by `python -m spectral_analyzer_amd.build --jni` only when
+ * JAVA_HOME is set):
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *       integration/jni/specgpu_jni.c -Lspectral_analyzer_amd/lib -lspecgpu \
+ *       -o spectral_analyzer_amd/lib/libspecgpu_jni.so
+ */
+#include <jni.h>
+#include <stdint.h>
+
+#include "specgpu.h"
+
+#define JNI_FN(name) Java_net_kcundercover_spectral_1analyzer_services_SpectralService_##name
+
+/* spec_status -> the exception the reference's own code path would raise */
+static void throw_status(JNIEnv *env, spec_ctx *ctx, spec_status st) {
+    const char *cls = "java/lang/RuntimeException";
+    if (st == SPEC_EINVAL) cls = "java/lang/IllegalArgumentException";         /* commons-math3 MathIllegalArgumentException */
+    else if (st == SPEC_ERANGE) cls = "java/lang/IndexOutOfBoundsException";  /* ByteBuffer absolute getters */
+    else if (st == SPEC_ENOMEM) cls = "java/lang/OutOfMemoryError";
+    else if (st == SPEC_EUNSUPPORTED) cls = "java/lang/UnsupportedOperationException";
+    jclass c = (*env)->FindClass(env, cls);
+    if (c) (*env)->ThrowNew(env, c, spec_last_error(ctx));
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(nativeCreate)(JNIEnv *env, jclass k, jint device, jint flags) {
+    (void)k;
+    spec_ctx *ctx = NULL;
+    spec_status st = spec_create(device, NULL, (uint32_t)flags, &ctx);
+    if (st != SPEC_OK) { throw_status(env, NULL, st); return 0; }
+    return (jlong)(intptr_t)ctx;
+}
+
+JNIEXPORT void JNICALL JNI_FN(nativeDestroy)(JNIEnv *env, jclass k, jlong h) {
+    (void)env; (void)k;
+    spec_destroy((spec_ctx *)(intptr_t)h);
+}
+
+/* double[] computeMagnitudes(MappedByteBuffer, int startByte, int nfft, String datatype) -- SS:33 */
+JNIEXPORT void JNICALL JNI_FN(nativeComputeMagnitudes)(JNIEnv *env, jclass k, jlong h, jobject buffer,
+                                                        jint startByte, jint nfft, jstring datatype,
+                                                        jboolean bigEndian, jdoubleArray out) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    void *base = (*env)->GetDirectBufferAddress(env, buffer);
+    jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
+    if (!base || cap < 0) { throw_status(env, ctx, SPEC_EINVAL); return; }
+    const char *dt = (*env)->GetStringUTFChars(env, datatype, NULL);
+    jdouble *o = (*env)->GetDoubleArrayElements(env, out, NULL);
+    spec_status st = spec_compute_magnitudes(ctx, base, (uint64_t)cap, (int64_t)startByte, (uint32_t)nfft, dt,
+                                             bigEndian ? 1 : 0, o);
+    (*env)->ReleaseDoubleArrayElements(env, out, o, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseStringUTFChars(env, datatype, dt);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
+/* batched MainController.updateDisplay loop (MC:980-999): float[nLines*nfft] */
+JNIEXPORT void JNICALL JNI_FN(nativeWaterfall)(JNIEnv *env, jclass k, jlong h, jobject buffer, jlong startByte,
+                                                jint dtype, jint nfft, jint hop, jlong nLines, jint window,
+                                                jdouble eofFill, jfloatArray out) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    void *base = (*env)->GetDirectBufferAddress(env, buffer);
+    jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
+    if (!base || cap < 0 || (jlong)(*env)->GetArrayLength(env, out) < nLines * (jlong)nfft) {
+        throw_status(env, ctx, SPEC_EINVAL);
+        return;
+    }
+    jfloat *o = (*env)->GetFloatArrayElements(env, out, NULL);
+    spec_status st = spec_waterfall(ctx, base, 0, (uint64_t)cap, (uint64_t)startByte, (spec_dtype)dtype,
+                                    (uint32_t)nfft, (uint32_t)hop, (uint64_t)nLines, (spec_window)window,
+                                    SPEC_OUT_DB20_F32, eofFill, o, 0);
+    (*env)->ReleaseFloatArrayElements(env, out, o, st == SPEC_OK ? 0 : JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
+/* PowerSpectralDensity.calculatePsdWelch call site (ADC:308-312): freq[nfft], psd[nfft] */
+JNIEXPORT void JNICALL JNI_FN(nativeWelch)(JNIEnv *env, jclass k, jlong h, jobject buffer, jlong startByte,
+                                            jint dtype, jint nfft, jint hop, jint nSeg, jint window, jint scaling,
+                                            jdouble fs, jboolean db, jdoubleArray freq, jfloatArray psd) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    void *base = (*env)->GetDirectBufferAddress(env, buffer);
+    jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
+    if (!base || cap < 0) { throw_status(env, ctx, SPEC_EINVAL); return; }
+    jdouble *f = (*env)->GetDoubleArrayElements(env, freq, NULL);
+    jfloat *p = (*env)->GetFloatArrayElements(env, psd, NULL);
+    spec_status st = spec_welch_psd(ctx, base, 0, (uint64_t)cap, (uint64_t)startByte, 0, 1, (spec_dtype)dtype,
+                                    (uint32_t)nfft, (uint32_t)hop, (uint32_t)nSeg, (spec_window)window,
+                                    (spec_psd_scaling)scaling, fs, db ? 1 : 0, f, p, 0);
+    (*env)->ReleaseFloatArrayElements(env, psd, p, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, freq, f, st == SPEC_OK ? 0 : JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
+JNIEXPORT jint JNICALL JNI_FN(nativeDtype)(JNIEnv *env, jclass k, jstring datatype) {
+    (void)k;
+    const char *dt = (*env)->GetStringUTFChars(env, datatype, NULL);
+    jint v = (jint)spec_dtype_from_sigmf(dt);
+    (*env)->ReleaseStringUTFChars(env, datatype, dt);
+    return v;
+}

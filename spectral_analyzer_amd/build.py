@@ -62,5 +62,28 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_jni(verbose: bool = False):
+    """Compile integration/jni/specgpu_jni.c when a JDK (jni.h) is present; returns the
+    path or None.  The authoring container has no JDK, so this is normally skipped --
+    loudly -- and the C ABI underneath is what tests and benchmarks drive."""
+    root = os.path.dirname(HERE)
+    jh = os.environ.get("JAVA_HOME", "")
+    inc = os.path.join(jh, "include")
+    if not jh or not os.path.exists(os.path.join(inc, "jni.h")):
+        if verbose:
+            print("JNI shim skipped: no JAVA_HOME/include/jni.h on this machine")
+        return None
+    out = os.path.join(LIBDIR, "libspecgpu_jni.so")
+    cmd = ["gcc", "-shared", "-fPIC", "-O2", "-I" + inc, "-I" + os.path.join(inc, "linux"),
+           "-I" + os.path.join(root, "include"), os.path.join(root, "integration", "jni", "specgpu_jni.c"),
+           "-L" + LIBDIR, "-lspecgpu", "-Wl,-rpath,$ORIGIN", "-o", out]
+    subprocess.check_call(cmd)
+    if verbose:
+        print("built", out)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    if "--jni" in sys.argv:
+        build_jni(verbose=True)

@@ -32,7 +32,7 @@ struct spec_ctx {
     void *stage_out = nullptr; size_t stage_out_bytes = 0;
     void *scratch = nullptr;   size_t scratch_bytes = 0;
     // tuning / testing knobs (spec_set_option)
-    int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_variant = 0;
+    int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_variant = 1;  // variant 1: non-temporal HBM accesses
     int n_cu = 256;
 };
 
@@ -325,10 +325,10 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         if (c->opt_lines_per_wg > 0) {
             a.lines_per_wg = (uint32_t)((c->opt_lines_per_wg + lpw - 1) / lpw * lpw);
         } else if (tuned) {
-            // Runs of 16 lines, handed out by the hardware dispatcher as workgroups
-            // retire: measured faster than one equal run per resident workgroup
-            // (tools/tune.py, profiles/): 1/16 of the input is re-read at run seams.
-            a.lines_per_wg = 16;
+            // Runs of 32 lines, handed out by the hardware dispatcher as workgroups
+            // retire: measured (tools/tune.py) a little faster than one equal run per
+            // resident workgroup; 1/32 of the input is read twice, at the run seams.
+            a.lines_per_wg = 32;
         } else {
             a.lines_per_wg = pick_lines_per_wg(rem, lpw);
         }
