@@ -106,11 +106,8 @@ spec_status spec_sync(spec_ctx *ctx);
 void *spec_stream(const spec_ctx *ctx);
 
 /* Tuning / testing knobs (not needed for normal use):
- *   "force_generic" = 1  route every request through the generic kernels
- *   "lines_per_wg"  = n  consecutive lines walked by one workgroup (0 = automatic)
- *   "variant"       = v  kernel variant bits of the tuned 4096-point path: bit 0 =
- *                        non-temporal loads/stores (default on), bits 1-2 = workgroups
- *                        per CU (0 automatic, 1 -> 4, 2 -> 3, 3 -> 2) */
+ *   "force_generic" = 1  route every request through the generic (scalar-math) kernels
+ *   "lines_per_wg"  = n  consecutive lines walked by one sub-line / workgroup (0 = automatic) */
 spec_status spec_set_option(spec_ctx *ctx, const char *key, int64_t value);
 
 /* ---- datatype table ------------------------------------------------------ */

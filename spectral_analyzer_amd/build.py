@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libspecgpu.so")
-SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_tuned.hip", "spec_k_large.hip", "spec_misc.hip"]
+SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_large.hip", "spec_k_v2s.hip", "spec_k_v2w.hip", "spec_misc.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(_compile, SOURCES))
     cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)

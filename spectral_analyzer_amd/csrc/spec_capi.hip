@@ -32,7 +32,7 @@ struct spec_ctx {
     void *stage_out = nullptr; size_t stage_out_bytes = 0;
     void *scratch = nullptr;   size_t scratch_bytes = 0;
     // tuning / testing knobs (spec_set_option)
-    int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_variant = 1;  // variant 1: non-temporal HBM accesses
+    int64_t opt_force_generic = 0, opt_lines_per_wg = 0;
     int n_cu = 256;
 };
 
@@ -184,7 +184,6 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     if (!key) return fail(c, SPEC_EINVAL, "spec_set_option: null key");
     if (!strcmp(key, "force_generic")) c->opt_force_generic = value;
     else if (!strcmp(key, "lines_per_wg")) c->opt_lines_per_wg = value < 0 ? 0 : value;
-    else if (!strcmp(key, "variant")) c->opt_variant = value;
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
     return SPEC_OK;
 }
@@ -220,9 +219,9 @@ static spec_status get_twiddles(spec_ctx *c, int log2n, bool f64, const void **o
 }
 
 static spec_status get_window(spec_ctx *c, int log2n, bool f64, spec_window w, const void **out, double *s1,
-                              double *s2) {
+                              double *s2, bool table_for_rect = false) {
     const size_t n = (size_t)1 << log2n;
-    if (w == SPEC_WIN_RECT) {
+    if (w == SPEC_WIN_RECT && !table_for_rect) {
         *out = nullptr;
         if (s1) *s1 = (double)n;
         if (s2) *s2 = (double)n;
@@ -236,7 +235,7 @@ static spec_status get_window(spec_ctx *c, int log2n, bool f64, spec_window w, c
         const long double two_pi = 6.283185307179586476925286766559005768L;
         double a1 = 0, a2 = 0;
         for (size_t i = 0; i < n; ++i) {
-            const double v = (double)(0.5L - 0.5L * cosl(two_pi * (long double)i / (long double)n));
+            const double v = w == SPEC_WIN_RECT ? 1.0 : (double)(0.5L - 0.5L * cosl(two_pi * (long double)i / (long double)n));
             a1 += v; a2 += v * v;
             if (f64) reinterpret_cast<double *>(host.data())[i] = v;
             else reinterpret_cast<float *>(host.data())[i] = (float)v;
@@ -317,28 +316,39 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         return SPEC_OK;
     }
     const int lpw = plan_lpw(log2n);
-    const bool tuned = !f64 && !c->opt_force_generic && tuned4096_applicable(a, log2n);
+    const bool v2 = !f64 && !c->opt_force_generic &&
+                    v2_applicable(log2n, a.kind, a.be, a.out_fmt, n_lines, hop);
+    if (v2) {
+        // packed-fp32 family: every sub-line (T threads) walks its own run of consecutive lines
+        const uint64_t sub = (uint64_t)v2_lpw(log2n);
+        uint64_t done = 0;
+        while (done < n_lines) {
+            const uint64_t rem = n_lines - done;
+            uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg
+                                                    : (rem + sub * c->n_cu * 8 - 1) / (sub * c->n_cu * 8);
+            if (run < 1) run = 1;
+            if (run > 32) run = 32;
+            const uint64_t max_lines = 0x7FFFFFFFull;  // 32-bit line index inside one launch
+            a.n_lines = rem < max_lines ? rem : max_lines;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_v2_spectro(a, log2n, (uint32_t)run, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "spectrogram launch: %s", hipGetErrorString(e));
+            done += a.n_lines;
+        }
+        return SPEC_OK;
+    }
     // one launch covers at most 2^31 - 1 workgroups; split very long recordings
     uint64_t done = 0;
     while (done < n_lines) {
         const uint64_t rem = n_lines - done;
-        if (c->opt_lines_per_wg > 0) {
-            a.lines_per_wg = (uint32_t)((c->opt_lines_per_wg + lpw - 1) / lpw * lpw);
-        } else if (tuned) {
-            // Runs of 32 lines, handed out by the hardware dispatcher as workgroups
-            // retire: measured (tools/tune.py) a little faster than one equal run per
-            // resident workgroup; 1/32 of the input is read twice, at the run seams.
-            a.lines_per_wg = 32;
-        } else {
-            a.lines_per_wg = pick_lines_per_wg(rem, lpw);
-        }
+        a.lines_per_wg = c->opt_lines_per_wg > 0 ? (uint32_t)((c->opt_lines_per_wg + lpw - 1) / lpw * lpw)
+                                                  : pick_lines_per_wg(rem, lpw);
         const uint64_t max_lines = (uint64_t)a.lines_per_wg * 0x7FFFFFFFull;
         a.n_lines = rem < max_lines ? rem : max_lines;
         a.iq = d_first + done * (uint64_t)hop * a.bps;
         a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
-        hipError_t e = tuned ? launch_spectro4096(a, (int)c->opt_variant, c->stream)
-                       : f64 ? launch_spectro_f64(a, log2n, c->stream)
-                             : launch_spectro_f32(a, log2n, c->stream);
+        hipError_t e = f64 ? launch_spectro_f64(a, log2n, c->stream) : launch_spectro_f32(a, log2n, c->stream);
         if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "spectrogram launch: %s", hipGetErrorString(e));
         done += a.n_lines;
     }
@@ -524,6 +534,41 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
     double s1 = 0, s2 = 0;
     st = get_window(c, log2n, false, window, &a.win, &s1, &s2);
     if (st != SPEC_OK) return st;
+    if (!c->opt_force_generic && v2_applicable(log2n, a.kind, a.be, OUT_POW_F32, n_seg, hop)) {
+        // packed-fp32 family: sub-lines accumulate |X|^2 over runs of segments, one slab each
+        st = get_window(c, log2n, false, window, &a.win, &s1, &s2, /*table_for_rect=*/true);
+        if (st != SPEC_OK) return st;
+        const uint32_t sub = (uint32_t)v2_lpw(log2n);
+        uint64_t run = ((uint64_t)n_seg * n_psd + (uint64_t)c->n_cu * 16 - 1) / ((uint64_t)c->n_cu * 16);
+        if (run < 4) run = 4;
+        if (run > 64) run = 64;
+        if (run > n_seg) run = n_seg;
+        const uint32_t wgs = (uint32_t)((n_seg + run * sub - 1) / (run * sub));
+        const uint32_t n_slabs = wgs * sub;
+        st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)n_psd * n_slabs * nfft * sizeof(float));
+        if (st != SPEC_OK) return st;
+        a.partial = static_cast<float *>(c->scratch);
+        float *d_out = psd_out;
+        if (!out_on_device) {
+            st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * sizeof(float));
+            if (st != SPEC_OK) return st;
+            d_out = static_cast<float *>(c->stage_out);
+        }
+        hipError_t e = launch_v2_welch(a, log2n, (uint32_t)run, wgs, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch launch: %s", hipGetErrorString(e));
+        const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
+        e = launch_welch_finalize(a.partial, n_psd, n_slabs, nfft, norm, db, d_out, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch finalize launch: %s", hipGetErrorString(e));
+        if (!out_on_device) {
+            HIP_TRY(c, hipMemcpyAsync(psd_out, d_out, (size_t)n_psd * nfft * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else if (!iq_on_device) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (freq_out)
+            for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
+        return SPEC_OK;
+    }
     const int lpw = plan_lpw(log2n);
     // enough workgroups to fill the chip when few PSDs are requested
     uint32_t chunks = (n_seg + lpw - 1) / lpw;  // at most one group of LPW segments per workgroup

@@ -55,6 +55,32 @@ __device__ __forceinline__ void pk_dft4_rot2(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
     x3 = pk_sub_mi(t1, d);
 }
 
+__device__ __forceinline__ void pk_dft2(v2f &a, v2f &b) {
+    const v2f t = a - b;
+    a = a + b;
+    b = t;
+}
+
+// 8-point forward DFT in place, natural order out: n = 2 n1 + n2, k = k1 + 4 k2
+__device__ __forceinline__ void pk_dft8(v2f (&u)[8]) {
+    constexpr float h = 0.70710678118654752440f;
+    pk_dft4(u[0], u[2], u[4], u[6]);  // A0[k1] -> slots 0,2,4,6
+    pk_dft4(u[1], u[3], u[5], u[7]);  // A1[k1] -> slots 1,3,5,7
+    const v2f a1 = pk_add_mi(u[3], u[3]) * v2f{h, h};    // A1[1] W8^1 = h(1 - i)
+    const v2f a3 = pk_sub_mi(u[7], u[7]) * v2f{-h, -h};  // A1[3] W8^3 = -h(1 + i)
+    v2f y[8];
+    y[0] = u[0] + u[1];
+    y[4] = u[0] - u[1];
+    y[1] = u[2] + a1;
+    y[5] = u[2] - a1;
+    y[2] = pk_add_mi(u[4], u[5]);                        // A1[2] W8^2 = -i folded in
+    y[6] = pk_sub_mi(u[4], u[5]);
+    y[3] = u[6] + a3;
+    y[7] = u[6] - a3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] = y[k];
+}
+
 // 16-point forward DFT in place, natural order out (same index algebra as
 // dft16 in spec_fft.h)
 __device__ __forceinline__ void pk_dft16(v2f (&u)[16]) {
@@ -87,6 +113,13 @@ __device__ __forceinline__ void pk_dft16(v2f (&u)[16]) {
         for (int k2 = 0; k2 < 4; ++k2) y[k1 + 4 * k2] = u[4 * k1 + k2];
 #pragma unroll
     for (int k = 0; k < 16; ++k) u[k] = y[k];
+}
+
+template <int RADIX> __device__ __forceinline__ void pk_dft(v2f (&u)[RADIX]) {
+    if constexpr (RADIX == 2) pk_dft2(u[0], u[1]);
+    else if constexpr (RADIX == 4) pk_dft4(u[0], u[1], u[2], u[3]);
+    else if constexpr (RADIX == 8) pk_dft8(u);
+    else pk_dft16(u);
 }
 
 }  // namespace specgpu

@@ -45,16 +45,18 @@ hipError_t launch_spectro_f32(const WfArgs &a, int log2n, hipStream_t s);
 hipError_t launch_spectro_f64(const WfArgs &a, int log2n, hipStream_t s);
 hipError_t launch_welch_f32(const WelchArgs &a, int log2n, hipStream_t s);
 
-// tuned 4096-point path (spec_k_tuned.hip); variant bit 0 = non-temporal loads/stores
-bool tuned4096_applicable(const WfArgs &a, int log2n);
-hipError_t launch_spectro4096(const WfArgs &a, int variant, hipStream_t s);
-
 // large-N four-step path (spec_k_large.hip): w.tw is the W_N table, tw1/tw2 the
 // W_N1 / W_N2 tables of the split, scratch holds n_lines * N complex values
 bool large_split(int log2n, bool f64, int *l1, int *l2);
 size_t large_scratch_bytes_per_line(int log2n, bool f64);
 hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2,
                                 void *scratch, hipStream_t s);
+
+// packed-fp32 family (spec_v2.h): every LDS-resident size, cf32/ci16/cu8/ci8 little endian
+bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, uint32_t hop);
+int v2_lpw(int log2n);  // sub-lines per workgroup
+hipError_t launch_v2_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream_t s);
+hipError_t launch_v2_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t wgs_per_unit, hipStream_t s);
 
 hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);
 hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs,

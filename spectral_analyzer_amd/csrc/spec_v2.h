@@ -1,0 +1,444 @@
+// spec_v2.h -- the packed-fp32 kernel family for every LDS-resident size
+// (nfft = 64 ... 16384) and the little-endian / byte datatypes (cf32, ci16, cu8,
+// ci8): spectrogram lines and Welch partial sums:
+//   * plans put the SMALL radix first (64 = 4x16 ... 16384 = 4x16x16x16) so that
+//     every pass but the last has few distinct twiddles (LDS tables, stored as
+//     (c, d, -d, d)) and the last pass is always one radix-16 butterfly per
+//     thread with its 15 twiddles W_N^(r t) in registers;
+//   * a line is owned by T = nfft/16 threads.  Up to 1024 points that is at most
+//     one wave, so the LDS exchanges are wave-local: no s_barrier at all;
+//   * every sub-line walks its own run of consecutive lines, so a hop of SH*T
+//     samples is a shift of SH registers and each input byte is fetched once;
+//   * buffer addressing with scalar offsets, packed complex math, prefetch of the
+//     next line behind the current FFT, epilogue with one range test per thread.
+#pragma once
+#include "spec_fft.h"
+#include "spec_fft_pk.h"
+#include "spec_internal.h"
+
+namespace specgpu {
+
+namespace {
+
+constexpr int E = 16;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int L> struct Plan2;
+#define SPEC_PLAN2(L, NP, ...)                                                        \
+    template <> struct Plan2<L> {                                                     \
+        static constexpr int N = 1 << L, T = N / E, NPASS = NP;                       \
+        static constexpr int radix[4] = {__VA_ARGS__};                                \
+        static constexpr int WG = T <= 64 ? 256 : T; /* threads per workgroup */      \
+        static constexpr int LPW = WG / T;           /* sub-lines per workgroup */    \
+        static constexpr bool WAVE_LOCAL = T <= 64;  /* exchanges stay inside a wave */ \
+        static constexpr int LINE = N + N / 16 + (T < 32 ? 16 : 0); /* LDS elements per sub-line, pads included */ \
+    };
+SPEC_PLAN2(6, 2, 4, 16, 1, 1)
+SPEC_PLAN2(7, 2, 8, 16, 1, 1)
+SPEC_PLAN2(8, 2, 16, 16, 1, 1)
+SPEC_PLAN2(9, 3, 2, 16, 16, 1)
+SPEC_PLAN2(10, 3, 4, 16, 16, 1)
+SPEC_PLAN2(11, 3, 8, 16, 16, 1)
+SPEC_PLAN2(12, 3, 16, 16, 16, 1)
+SPEC_PLAN2(13, 4, 2, 16, 16, 16)
+SPEC_PLAN2(14, 4, 4, 16, 16, 16)
+#undef SPEC_PLAN2
+
+template <int L> constexpr int p2_P_of(int pass) {  // product of the radices before `pass`
+    int p = 1;
+    for (int q = 0; q < pass; ++q) p *= Plan2<L>::radix[q];
+    return p;
+}
+template <int L, int PASS> constexpr int p2_P() { return p2_P_of<L>(PASS); }
+// LDS twiddle tables of the middle passes 1 .. NPASS-2: entry (r, k) of pass z at
+// off(z) + r*P_z + k, in v4f units
+template <int L> constexpr int p2_tab_size(int pass) { return Plan2<L>::radix[pass] * p2_P_of<L>(pass); }
+template <int L> constexpr int p2_tab_off_of(int pass) {
+    int o = 0;
+    for (int q = 1; q < pass; ++q) o += p2_tab_size<L>(q);
+    return o;
+}
+template <int L, int PASS> constexpr int p2_tab_off() { return p2_tab_off_of<L>(PASS); }
+template <int L> constexpr int p2_tab_entries() { return p2_tab_off_of<L>(Plan2<L>::NPASS - 1); }
+template <int L> constexpr size_t p2_lds_bytes() {
+    return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * 8 + (size_t)p2_tab_entries<L>() * 16;
+}
+
+// ---- raw sample formats (SS:40-59); SCALE is folded into the epilogue -------------
+template <int KIND> struct Raw2;
+template <> struct Raw2<K_CF32> {
+    using type = u32x2;
+    static constexpr int BPS = 8;
+    static constexpr float SCALE = 1.0f;
+    template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, v, s, AUX);
+    }
+    static __device__ __forceinline__ v2f dec(type u) { return v2f{__uint_as_float(u.x), __uint_as_float(u.y)}; }
+};
+template <> struct Raw2<K_CI16> {
+    using type = uint32_t;
+    static constexpr int BPS = 4;
+    static constexpr float SCALE = 1.0f / 32768.0f;  // SS:44-45
+    template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
+        return __builtin_amdgcn_raw_buffer_load_b32(r, v, s, AUX);
+    }
+    static __device__ __forceinline__ v2f dec(type u) {
+        return v2f{(float)(int16_t)(u & 0xFFFFu), (float)((int32_t)u >> 16)};
+    }
+};
+template <> struct Raw2<K_CI8> {
+    using type = uint16_t;
+    static constexpr int BPS = 2;
+    static constexpr float SCALE = 1.0f / 128.0f;  // SS:58-59
+    template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
+        return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, v, s, AUX);
+    }
+    static __device__ __forceinline__ v2f dec(type u) { return v2f{(float)(int8_t)(u & 0xFF), (float)(int8_t)(u >> 8)}; }
+};
+template <> struct Raw2<K_CU8> {
+    using type = uint16_t;
+    static constexpr int BPS = 2;
+    static constexpr float SCALE = 1.0f / 128.0f;  // SS:53-54: (b - 127.5) / 128
+    template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
+        return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, v, s, AUX);
+    }
+    static __device__ __forceinline__ v2f dec(type u) {
+        return v2f{(float)(u & 0xFF), (float)(u >> 8)} - v2f{127.5f, 127.5f};
+    }
+};
+
+// LDS layout of an exchange written with a stride narrower than 16 elements: one
+// pad element after every 16, index a -> a + (a >> 4).  The 16 lanes of a write
+// group then hit 16 different 8-byte slots, the stride-T read loses one cycle to
+// a single 2-way conflict (tools/lds_sim.py), and -- unlike an XOR swizzle -- every
+// address splits into a per-thread base plus a compile-time immediate, so an
+// exchange costs two address registers and no VALU work.
+constexpr int pad16(int a) { return a + (a >> 4); }
+__device__ __forceinline__ int pad16_rt(int a) { return a + (a >> 4); }
+
+// One pass on the registers.  Middle passes take their twiddles from the LDS
+// table `tab` (entry (r, k) at r*P + k, as (c, d, -d, d)); the last pass from
+// the per-thread registers `twl`.
+template <int L, int PASS>
+__device__ __forceinline__ void v2_pass(v2f (&v)[E], int t, const v4f *tab, v2f (&twl)[E]) {
+    using PL = Plan2<L>;
+    constexpr int R = PL::radix[PASS], S = E / R, P = p2_P<L, PASS>();
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        v2f u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = v[s + r * S];
+        if constexpr (PASS == PL::NPASS - 1) {
+            static_assert(R == 16 && S == 1, "last pass is one radix-16 butterfly");
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                asm volatile("" : "+v"(twl[r]));  // keep (c, d) only: stops hipcc hoisting 15 derived (-d, d) pairs
+                u[r] = pk_cmul(u[r], twl[r]);
+            }
+        } else if constexpr (PASS > 0) {
+            const int k = (t + s * PL::T) & (P - 1);
+            const v4f *row = tab + p2_tab_off<L, PASS>() + k;
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const v4f q = row[r * P];
+                u[r] = pk_cmul_pre(u[r], v2f{q.x, q.y}, v2f{q.z, q.w});
+            }
+        }
+        pk_dft<R>(u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[s + r * S] = u[r];
+    }
+}
+
+// registers -> LDS after PASS.  Index of output r of butterfly i = t + s T:
+//   hi*(R P) + r P + k,  k = i mod P, hi = i / P      (Stockham autosort)
+template <int L, int PASS> __device__ __forceinline__ void v2_store(const v2f (&v)[E], int t, v2f *lds) {
+    using PL = Plan2<L>;
+    constexpr int R = PL::radix[PASS], S = E / R, P = p2_P<L, PASS>();
+    if constexpr (P >= 16) {  // wide stride: plain layout is conflict free
+        static_assert(S == 1, "only the first pass has several butterflies per thread");
+        v2f *base = lds + ((t & ~(P - 1)) * R + (t & (P - 1)));
+#pragma unroll
+        for (int r = 0; r < R; ++r) base[r * P] = v[r];
+    } else if constexpr (PASS == 0) {  // P == 1: a = i R + r, padded: pad(t R) + s*pad(T R) + r
+        static_assert((PL::T * R) % 16 == 0, "sub-line stride must be a multiple of 16 elements");
+        v2f *base = lds + pad16_rt(t * R);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int r = 0; r < R; ++r) base[pad16(s * PL::T * R) + r] = v[s + r * S];
+    } else {  // 1 < P < 16, R = 16, S = 1: hi*(17 P) + k + pad(r P)
+        static_assert(S == 1 && R == 16, "middle passes are single radix-16 butterflies");
+        v2f *base = lds + ((t / P) * (17 * P) + (t & (P - 1)));
+#pragma unroll
+        for (int r = 0; r < R; ++r) base[pad16(r * P)] = v[r];
+    }
+}
+// LDS -> registers at stride T after the exchange written by PASS
+template <int L, int PASS> __device__ __forceinline__ void v2_load(v2f (&v)[E], int t, const v2f *lds) {
+    using PL = Plan2<L>;
+    if constexpr (p2_P<L, PASS>() >= 16) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = lds[t + m * PL::T];
+    } else {
+        const v2f *base = lds + (PL::T >= 16 ? pad16_rt(t) : t);
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = base[pad16(m * PL::T)];
+    }
+}
+
+// W_N^(r k STEP) for the (r, k) of one middle pass, as (c, d, -d, d)
+template <int L, int PASS> __device__ __forceinline__ void fill_tables(v4f *tab, const v2f *__restrict__ tw, int tid) {
+    using PL = Plan2<L>;
+    if constexpr (PASS < PL::NPASS - 1) {
+        constexpr int P = p2_P<L, PASS>(), R = PL::radix[PASS], STEP = PL::N / (P * R);
+        for (int e = tid; e < R * P; e += PL::WG) {
+            const v2f w0 = tw[(e / P) * (e % P) * STEP];
+            tab[p2_tab_off<L, PASS>() + e] = v4f{w0.x, w0.y, -w0.y, w0.y};
+        }
+        fill_tables<L, PASS + 1>(tab, tw, tid);
+    }
+}
+
+template <int L> __device__ __forceinline__ void v2_sync() {
+    if constexpr (Plan2<L>::WAVE_LOCAL) {
+        // the line's LDS region belongs to lanes of this wave only and a wave's DS
+        // operations complete in issue order: a scheduling fence is all it takes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int L, int PASS = 0>
+__device__ __forceinline__ void v2_fft(v2f (&v)[E], int t, v2f *lds, const v4f *tab, v2f (&twl)[E]) {
+    using PL = Plan2<L>;
+    v2_pass<L, PASS>(v, t, tab, twl);
+    if constexpr (PASS + 1 < PL::NPASS) {
+        v2_sync<L>();  // WAR: the previous exchange has been read by everyone
+        v2_store<L, PASS>(v, t, lds);
+        v2_sync<L>();
+        v2_load<L, PASS>(v, t, lds);
+        v2_fft<L, PASS + 1>(v, t, lds, tab, twl);
+    }
+}
+
+// 20 log10(|X| + 1e-10) of the spectrum
+// scale * v (SS:80-81), one range test per thread
+template <bool DB> __device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, float (&d)[E]) {
+    float p[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const v2f s = v[m] * v[m];
+        p[m] = s.x + s.y;
+    }
+    const float s2 = scale * scale;
+    if constexpr (!DB) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) d[m] = p[m] * s2;
+    } else {
+        float lo = fminf(fminf(p[0], p[1]), p[2]), hi = fmaxf(fmaxf(p[0], p[1]), p[2]);
+#pragma unroll
+        for (int m = 3; m + 1 < E; m += 2) { lo = fminf(fminf(lo, p[m]), p[m + 1]); hi = fmaxf(fmaxf(hi, p[m]), p[m + 1]); }
+        lo = fminf(lo, p[E - 1]);
+        hi = fmaxf(hi, p[E - 1]);
+        constexpr float k10 = 3.01029995663981195f;
+        const float off = k10 * __log2f(s2);
+        if (lo * s2 > 1e-4f && hi < 1e37f) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) d[m] = __builtin_fmaf(k10, __log2f(p[m]), off);
+        } else {
+#pragma unroll
+            for (int m = 0; m < E; ++m) d[m] = db20(cx<float>{v[m].x * scale, v[m].y * scale});
+        }
+    }
+}
+
+struct V2Args {
+    const uint8_t *iq;      // first byte of unit 0, line 0
+    uint64_t unit_stride;   // bytes between units (Welch: PSDs; spectrogram: one unit)
+    uint32_t n_units, n_lines;  // lines (segments) per unit
+    uint32_t hop, run;      // samples between lines; lines per sub-line run
+    uint32_t wgs_per_unit;
+    const void *tw, *win;
+    void *out;              // spectrogram: float[n_lines][N]; Welch: float slabs [unit][wg*LPW + q][N]
+    int out_fmt;
+};
+
+// MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums
+template <int L, int KIND, int SH, bool HAS_WIN, int MODE, int OCC>
+__global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
+    using PL = Plan2<L>;
+    using RW = Raw2<KIND>;
+    using raw_t = typename RW::type;
+    constexpr int BPS = RW::BPS, N = PL::N, T = PL::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, t = tid % T, q = tid / T;
+    v2f *lds = reinterpret_cast<v2f *>(smem) + (size_t)q * PL::LINE;
+    v4f *tab = reinterpret_cast<v4f *>(smem + (size_t)PL::LPW * PL::LINE * 8);
+    const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw);
+
+    // ---- one-time set-up: LDS twiddle tables of the middle passes, last-pass registers
+    if constexpr (PL::NPASS > 2) fill_tables<L, 1>(tab, tw, tid);
+    v2f twl[E];
+#pragma unroll
+    for (int r = 1; r < E; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    float w[E];
+    if constexpr (HAS_WIN) {
+        const float *__restrict__ win = static_cast<const float *>(a.win);
+#pragma unroll
+        for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
+    }
+    if constexpr (PL::NPASS > 2) __syncthreads();
+
+    // ---- this workgroup's span: LPW consecutive runs of `run` lines of one unit
+    const uint32_t unit = blockIdx.x / a.wgs_per_unit, wg = blockIdx.x % a.wgs_per_unit;
+    const uint32_t line0 = wg * (uint32_t)PL::LPW * a.run;           // first line of the workgroup
+    uint32_t lines_wg = a.n_lines - line0;                            // valid lines from there on
+    if (lines_wg > (uint32_t)PL::LPW * a.run) lines_wg = PL::LPW * a.run;
+    const uint32_t line_bytes = a.hop * BPS;
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.iq) + (uint64_t)unit * a.unit_stride + (uint64_t)line0 * line_bytes, 0,
+        (lines_wg - 1) * line_bytes + (uint32_t)N * BPS, 0x00020000);
+    const int voff = (int)(q * a.run * line_bytes) + t * BPS;  // this sub-line's run, this thread's column
+    constexpr int AUX = 2;                                      // non-temporal
+    // overlap shift: SH > 0 promises hop == SH * T, i.e. the line slides by SH registers
+    constexpr int NEW = SH > 0 ? SH : E;
+
+    raw_t raw[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, m * T * BPS);
+
+    float acc[E];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) acc[m] = 0.0f;
+    }
+    __amdgpu_buffer_rsrc_t dst;
+    int ovoff = 0;
+    if constexpr (MODE == 0) {
+        dst = __builtin_amdgcn_make_buffer_rsrc(static_cast<float *>(a.out) + (uint64_t)line0 * N, 0,
+                                                lines_wg * (uint32_t)N * 4u, 0x00020000);
+        ovoff = (int)(q * a.run * (uint32_t)N * 4u) + t * 4;
+    }
+    // sub-lines whose run lies past the end read zeros and store nothing (descriptor bounds)
+    const uint32_t my_first = q * a.run;
+    const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
+    const uint32_t iters = PL::WAVE_LOCAL ? a.run : my_lines;  // whole-workgroup lines: LPW == 1
+
+    for (uint32_t line = 0; line < iters; ++line) {
+        v2f v[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            v[m] = RW::dec(raw[m]);
+            if constexpr (HAS_WIN) v[m] *= v2f{w[m], w[m]};
+        }
+        if constexpr (SH > 0 && SH < E) {
+#pragma unroll
+            for (int m = 0; m < E - SH; ++m) raw[m] = raw[m + SH];
+        }
+        const int next_off = (int)((line + 1) * line_bytes);
+#pragma unroll
+        for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
+
+        v2_fft<L>(v, t, lds, tab, twl);
+
+        if constexpr (MODE == 1) {
+            if (line < my_lines) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const v2f s = v[m] * v[m];
+                    acc[m] += s.x + s.y;
+                }
+            }
+        } else {
+            float d[E];
+            if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true>(v, RW::SCALE, d);
+            else v2_epilogue<false>(v, RW::SCALE, d);
+            const int out_off = (int)(line * (uint32_t)N * 4u);
+#pragma unroll
+            for (int m = 0; m < E; ++m)  // (t + m T + N/2) mod N   (SS:78)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, ovoff,
+                                                      out_off + ((m + E / 2) & (E - 1)) * T * 4, AUX);
+        }
+    }
+    if constexpr (MODE == 1) {
+        // one fp32 slab per sub-line (zeros for idle ones); welch_finalize_kernel sums them in order
+        float *slab = static_cast<float *>(a.out) + ((uint64_t)blockIdx.x * PL::LPW + q) * N;
+        constexpr float s2 = RW::SCALE * RW::SCALE;
+#pragma unroll
+        for (int m = 0; m < E; ++m) slab[t + m * T] = acc[m] * s2;
+    }
+}
+
+template <int L, int KIND, int SH, bool HAS_WIN, int MODE> hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
+    using PL = Plan2<L>;
+    constexpr size_t lds = p2_lds_bytes<L>();
+    // Minimum waves per SIMD asked of the register allocator, chosen so that the kernel does
+    // not spill: about 104 VGPRs of FFT state + 32 (cf32) or 16 raw sample registers + 16 for a
+    // window + 16 for Welch sums.  1024-thread groups need 4 (128 VGPRs) to exist at all.
+    constexpr int NEED = 104 + (KIND == K_CF32 ? 32 : 16) + (HAS_WIN ? 16 : 0) + (MODE == 1 ? 16 : 0);
+    constexpr int WAVES_PER_SIMD = PL::WG == 1024 ? 4 : PL::WG == 512 ? 2 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : 2;
+    auto kern = v2_kernel<L, KIND, SH, HAS_WIN, MODE, WAVES_PER_SIMD>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_units * a.wgs_per_unit), dim3(PL::WG), lds, s, a);
+    return hipGetLastError();
+}
+
+// Instantiation matrix: cf32 / ci16 carry the register-reuse variants (hop = 8 T and 4 T,
+// i.e. 50 % and 75 % overlap); the byte formats and every other hop take SH = 0.
+// Welch always multiplies by a window table (all ones for the rectangular window).
+template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hipStream_t s) {
+    constexpr int T = Plan2<L>::T;
+    constexpr bool FAST = KIND == K_CF32 || KIND == K_CI16;
+    if constexpr (MODE == 1) {
+        if constexpr (FAST) {
+            if (a.hop == 8 * T) return v2_launch1<L, KIND, 8, true, 1>(a, s);
+            if (a.hop == 4 * T) return v2_launch1<L, KIND, 4, true, 1>(a, s);
+        }
+        return v2_launch1<L, KIND, 0, true, 1>(a, s);
+    } else {
+        const bool win = a.win != nullptr;
+        if constexpr (FAST) {
+            if (a.hop == 8 * T) return win ? v2_launch1<L, KIND, 8, true, 0>(a, s) : v2_launch1<L, KIND, 8, false, 0>(a, s);
+            if (a.hop == 4 * T) return win ? v2_launch1<L, KIND, 4, true, 0>(a, s) : v2_launch1<L, KIND, 4, false, 0>(a, s);
+        }
+        return win ? v2_launch1<L, KIND, 0, true, 0>(a, s) : v2_launch1<L, KIND, 0, false, 0>(a, s);
+    }
+}
+
+template <int L, int MODE> hipError_t v2_launch_kind(const V2Args &a, int kind, hipStream_t s) {
+    switch (kind) {
+    case K_CF32: return v2_launch_sh<L, K_CF32, MODE>(a, s);
+    case K_CI16: return v2_launch_sh<L, K_CI16, MODE>(a, s);
+    case K_CU8: return v2_launch_sh<L, K_CU8, MODE>(a, s);
+    case K_CI8: return v2_launch_sh<L, K_CI8, MODE>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MODE> hipError_t v2_launch_n(const V2Args &a, int log2n, int kind, hipStream_t s) {
+    switch (log2n) {
+    case 6: return v2_launch_kind<6, MODE>(a, kind, s);
+    case 7: return v2_launch_kind<7, MODE>(a, kind, s);
+    case 8: return v2_launch_kind<8, MODE>(a, kind, s);
+    case 9: return v2_launch_kind<9, MODE>(a, kind, s);
+    case 10: return v2_launch_kind<10, MODE>(a, kind, s);
+    case 11: return v2_launch_kind<11, MODE>(a, kind, s);
+    case 12: return v2_launch_kind<12, MODE>(a, kind, s);
+    case 13: return v2_launch_kind<13, MODE>(a, kind, s);
+    case 14: return v2_launch_kind<14, MODE>(a, kind, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+}  // namespace specgpu

@@ -52,32 +52,30 @@ def test_waterfall_matches_oracle(svc, oracle, datatype, nfft):
     check_fp32(got, ref, nfft)   # cf64 input runs in fp64 but DB20_F32 output rounds to float
 
 
-# the tuned 4096-point kernel (spec_k_tuned.hip): every variant, all three hops, runs long
-# enough to exercise the register sliding window, both datatypes, with and without window
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7])
+# the headline configuration: runs long enough to exercise the register sliding window, several
+# run lengths (lines per sub-line), both fast datatypes
 @pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le"])
-def test_tuned4096_variants(svc, oracle, datatype, variant):
-    nfft, hop, n_lines = 4096, 2048, 75
+@pytest.mark.parametrize("nfft", [1024, 4096, 8192])
+def test_run_lengths(svc, oracle, datatype, nfft):
+    hop, n_lines = nfft // 2, 75
     iq = oracle.synth_iq(datatype, seed=77, first_sample=5, n_samples=(n_lines - 1) * hop + nfft)
     ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines)
     import torch
     d_iq = torch.from_numpy(iq).cuda()
-    svc.set_option("variant", variant)
     try:
-        for lpw in (0, 7, 75, 200):
+        for lpw in (0, 1, 7, 75, 200):
             svc.set_option("lines_per_wg", lpw)
             got = svc.compute_waterfall(d_iq, 0, nfft, datatype, n_lines, hop=hop)
             torch.cuda.synchronize()
             check_fp32(got.cpu().numpy(), ref, nfft)
     finally:
-        svc.set_option("variant", 1)     # the default
         svc.set_option("lines_per_wg", 0)
 
 
 @pytest.mark.parametrize("hop", [1024, 2048, 4096])
 @pytest.mark.parametrize("window", [sa.WIN_RECT, sa.WIN_HANN])
 @pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le"])
-def test_tuned4096_hops_windows(svc, oracle, datatype, window, hop):
+def test_4096_hops_windows(svc, oracle, datatype, window, hop):
     nfft, n_lines = 4096, 41
     iq = oracle.synth_iq(datatype, seed=hop + window, first_sample=0, n_samples=(n_lines - 1) * hop + nfft)
     ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window)

@@ -45,7 +45,7 @@ for _ in range(12):
 for rnd in range(args.rounds + 1):
     for name, v, l in cfgs:
         svc.set_option("force_generic", 1 if v is None else 0)
-        svc.set_option("variant", v or 0); svc.set_option("lines_per_wg", l)
+        svc.set_option("lines_per_wg", l)
         evs = []
         for rep in range(4):   # back-to-back, keep the last 3
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
