@@ -55,6 +55,10 @@ __device__ __forceinline__ void pk_dft4_rot2(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
     x3 = pk_sub_mi(t1, d);
 }
 
+// |a|^2 with scalar mul + fma: two instructions per bin.  (Left as v2f arithmetic hipcc packs two
+// bins per v_pk_mul_f32 and then spends four v_mov on the transposition: 3.5 per bin.)
+__device__ __forceinline__ float pk_norm(v2f a) { return __builtin_fmaf(a.x, a.x, a.y * a.y); }
+
 __device__ __forceinline__ void pk_dft2(v2f &a, v2f &b) {
     const v2f t = a - b;
     a = a + b;

@@ -231,10 +231,7 @@ __device__ __forceinline__ void v2_fft(v2f (&v)[E], int t, v2f *lds, const v4f *
 template <bool DB> __device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, float (&d)[E]) {
     float p[E];
 #pragma unroll
-    for (int m = 0; m < E; ++m) {
-        const v2f s = v[m] * v[m];
-        p[m] = s.x + s.y;
-    }
+    for (int m = 0; m < E; ++m) p[m] = pk_norm(v[m]);
     const float s2 = scale * scale;
     if constexpr (!DB) {
 #pragma unroll
@@ -329,7 +326,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
     const uint32_t iters = PL::WAVE_LOCAL ? a.run : my_lines;  // whole-workgroup lines: LPW == 1
 
-    for (uint32_t line = 0; line < iters; ++line) {
+    auto do_line = [&](uint32_t line) {
         v2f v[E];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
@@ -349,10 +346,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
         if constexpr (MODE == 1) {
             if (line < my_lines) {
 #pragma unroll
-                for (int m = 0; m < E; ++m) {
-                    const v2f s = v[m] * v[m];
-                    acc[m] += s.x + s.y;
-                }
+                for (int m = 0; m < E; ++m) acc[m] += pk_norm(v[m]);
             }
         } else {
             float d[E];
@@ -364,7 +358,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, ovoff,
                                                       out_off + ((m + E / 2) & (E - 1)) * T * 4, AUX);
         }
-    }
+    };
+    for (uint32_t line = 0; line < iters; ++line) do_line(line);
     if constexpr (MODE == 1) {
         // one fp32 slab per sub-line (zeros for idle ones); welch_finalize_kernel sums them in order
         float *slab = static_cast<float *>(a.out) + ((uint64_t)blockIdx.x * PL::LPW + q) * N;
