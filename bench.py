@@ -174,6 +174,33 @@ def main() -> None:
             "parity_spot_check": checked,
         }
         print(json.dumps(res), flush=True)
+    # outside the timed region: the tile gather of SURVEY 8(e) on a bounded slice (the first
+    # <= 4096 lines of every rank) through direct peer -> root sends; reported on stderr AFTER the bench line is out, never part of `value`
+    if dist is not None:
+        try:
+            gl = min(n_lines, 4096)
+            tile = out[:gl]
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = time.perf_counter()
+            if rank == 0:
+                full = torch.empty((gl * world, nfft), dtype=out.dtype, device=out.device)
+                full[:gl].copy_(tile)
+                ops = [dist.P2POp(dist.irecv, full[r * gl:(r + 1) * gl], r) for r in range(1, world)]
+            else:
+                ops = [dist.P2POp(dist.isend, tile, 0)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            torch.cuda.synchronize()
+            dist.barrier()
+            gms = (time.perf_counter() - g0) * 1e3
+            if rank == 0:
+                print(json.dumps({"gather": {"lines_per_rank": gl, "ms": gms,
+                                             "GBps_into_root": (world - 1) * gl * nfft * 4 / gms / 1e6}}),
+                      file=sys.stderr, flush=True)
+        except Exception as e:  # the demonstration must never break the run
+            print("gather demonstration failed: %r" % (e,), file=sys.stderr, flush=True)
+
     if dist is not None:
         dist.destroy_process_group()
 

@@ -539,8 +539,10 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
         st = get_window(c, log2n, false, window, &a.win, &s1, &s2, /*table_for_rect=*/true);
         if (st != SPEC_OK) return st;
         const uint32_t sub = (uint32_t)v2_lpw(log2n);
-        uint64_t run = ((uint64_t)n_seg * n_psd + (uint64_t)c->n_cu * 16 - 1) / ((uint64_t)c->n_cu * 16);
-        if (run < 4) run = 4;
+        // enough sub-lines to fill the chip first (a single 256-segment PSD gets one segment per
+        // sub-line), long runs (register reuse, fewer slabs) once there is plenty of work
+        uint64_t run = ((uint64_t)n_seg * n_psd) / ((uint64_t)c->n_cu * 8 * sub);
+        if (run < 1) run = 1;
         if (run > 64) run = 64;
         if (run > n_seg) run = n_seg;
         const uint32_t wgs = (uint32_t)((n_seg + run * sub - 1) / (run * sub));

@@ -283,9 +283,12 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     v2f twl[E];
 #pragma unroll
     for (int r = 1; r < E; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    // window values of this thread's 16 samples: registers, except for 16384 points (no room:
+    // re-read from the L2-resident table every line)
+    constexpr bool WIN_REGS = HAS_WIN && L < 14;
+    const float *win = static_cast<const float *>(a.win);
     float w[E];
-    if constexpr (HAS_WIN) {
-        const float *__restrict__ win = static_cast<const float *>(a.win);
+    if constexpr (WIN_REGS) {
 #pragma unroll
         for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
     }
@@ -305,9 +308,15 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     // overlap shift: SH > 0 promises hop == SH * T, i.e. the line slides by SH registers
     constexpr int NEW = SH > 0 ? SH : E;
 
+    // 16384-point lines run in 1024-thread workgroups (128 VGPRs): no room to keep a line's raw
+    // samples across iterations, so they are fetched at the top of each line (overlap comes
+    // from L2) and the 16 resident waves cover the latency instead of a prefetch.
+    constexpr bool KEEP = L < 14;
     raw_t raw[E];
+    if constexpr (KEEP) {
 #pragma unroll
-    for (int m = 0; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, m * T * BPS);
+        for (int m = 0; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, m * T * BPS);
+    }
 
     float acc[E];
     if constexpr (MODE == 1) {
@@ -328,18 +337,30 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 
     auto do_line = [&](uint32_t line) {
         v2f v[E];
+        if constexpr (!KEEP) {
+            const int off = (int)(line * line_bytes);
+#pragma unroll
+            for (int m = 0; m < E; ++m) raw[m] = RW::template load<0>(src, voff, off + m * T * BPS);
+        }
+        if constexpr (HAS_WIN && !WIN_REGS) {
+            asm volatile("" : "+s"(win));  // keep the loads inside the loop (LICM would pin 16 VGPRs)
+#pragma unroll
+            for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
+        }
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             v[m] = RW::dec(raw[m]);
             if constexpr (HAS_WIN) v[m] *= v2f{w[m], w[m]};
         }
-        if constexpr (SH > 0 && SH < E) {
+        if constexpr (KEEP) {
+            if constexpr (SH > 0 && SH < E) {
 #pragma unroll
-            for (int m = 0; m < E - SH; ++m) raw[m] = raw[m + SH];
+                for (int m = 0; m < E - SH; ++m) raw[m] = raw[m + SH];
+            }
+            const int next_off = (int)((line + 1) * line_bytes);
+#pragma unroll
+            for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
         }
-        const int next_off = (int)((line + 1) * line_bytes);
-#pragma unroll
-        for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
 
         v2_fft<L>(v, t, lds, tab, twl);
 
