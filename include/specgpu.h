@@ -162,6 +162,8 @@ spec_status spec_waterfall(spec_ctx *ctx, const void *iq, int iq_on_device, uint
  * reference tree, so window / overlap / scaling are explicit parameters here).
  * n_psd independent PSDs are computed in one call: PSD b uses n_seg segments
  * of nfft samples, hop apart, starting at byte start_byte + b*psd_stride_bytes.
+ * Any datatype and any nfft of the spectrogram path; cf32 / ci16 / cu8 / ci8 with
+ * 256 <= nfft <= 16384 take the fused fast path.
  * freq_out (may be NULL): nfft doubles, (k - nfft/2) fs / nfft, HOST memory.
  * psd_out: n_psd x nfft floats (fftshifted; 10 log10(P + 1e-20) when db != 0),
  * device memory when out_on_device != 0. */
@@ -170,6 +172,15 @@ spec_status spec_welch_psd(spec_ctx *ctx, const void *iq, int iq_on_device, uint
                            spec_dtype dt, uint32_t nfft, uint32_t hop, uint32_t n_seg,
                            spec_window window, spec_psd_scaling scaling, double fs, int db,
                            double *freq_out, float *psd_out, int out_on_device);
+
+/* The same estimate for the exact argument shape of the reference call
+ *   PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft)
+ * (AnalysisDialogController.java:308-312): planar doubles data[0] = I, data[1] = Q, host
+ * memory, as produced by ExtractDownConvertService.  Every whole segment of the signal is used
+ * (n_seg = (n_samples - nfft)/hop + 1); fp64 pipeline.  freq_out / psd_out: nfft values, host. */
+spec_status spec_welch_psd_planar_f64(spec_ctx *ctx, const double *re, const double *im, uint64_t n_samples,
+                                      uint32_t nfft, uint32_t hop, spec_window window, spec_psd_scaling scaling,
+                                      double fs, int db, double *freq_out, float *psd_out);
 
 /* ---- synthetic input (bench / tests) -------------------------- */
 

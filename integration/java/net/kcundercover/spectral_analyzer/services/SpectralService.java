@@ -76,6 +76,23 @@ public class SpectralService implements AutoCloseable {
         return new double[][] {freq, wide};
     }
 
+    /**
+     * Same argument shape as {@code PowerSpectralDensity.calculatePsdWelch(data, fs, nfft)} in the
+     * PSD dialog: {@code data[0]} = I, {@code data[1]} = Q.  Hann window, 50 % overlap, density
+     * scaling, linear power; returns {frequency axis, psd}.
+     */
+    public double[][] calculatePsdWelch(double[][] data, double sampleRate, int nfft) {
+        double[] freq = new double[nfft];
+        float[] psd = new float[nfft];
+        nativeWelchPlanar(handle, data[0], data[1], nfft, nfft / 2, WINDOW_HANN, PSD_DENSITY, sampleRate,
+                false, freq, psd);
+        double[] wide = new double[nfft];
+        for (int i = 0; i < nfft; i++) {
+            wide[i] = psd[i];
+        }
+        return new double[][] {freq, wide};
+    }
+
     @Override
     public void close() {
         nativeDestroy(handle);
@@ -90,5 +107,8 @@ public class SpectralService implements AutoCloseable {
     private static native void nativeWelch(long handle, ByteBuffer buffer, long startByte, int dtype, int nfft,
                                            int hop, int segments, int window, int scaling, double sampleRate,
                                            boolean decibel, double[] freq, float[] psd);
+    private static native void nativeWelchPlanar(long handle, double[] re, double[] im, int nfft, int hop,
+                                                 int window, int scaling, double sampleRate, boolean decibel,
+                                                 double[] freq, float[] psd);
     private static native int nativeDtype(String datatype);
 }

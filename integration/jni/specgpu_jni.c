@@ -103,6 +103,27 @@ JNIEXPORT void JNICALL JNI_FN(nativeWelch)(JNIEnv *env, jclass k, jlong h, jobje
     if (st != SPEC_OK) throw_status(env, ctx, st);
 }
 
+/* PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft) -- ADC:308-312 */
+JNIEXPORT void JNICALL JNI_FN(nativeWelchPlanar)(JNIEnv *env, jclass k, jlong h, jdoubleArray re, jdoubleArray im,
+                                                  jint nfft, jint hop, jint window, jint scaling, jdouble fs,
+                                                  jboolean db, jdoubleArray freq, jfloatArray psd) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    jsize n = (*env)->GetArrayLength(env, re);
+    if ((*env)->GetArrayLength(env, im) != n) { throw_status(env, ctx, SPEC_EINVAL); return; }
+    jdouble *r = (*env)->GetDoubleArrayElements(env, re, NULL);
+    jdouble *i = (*env)->GetDoubleArrayElements(env, im, NULL);
+    jdouble *f = (*env)->GetDoubleArrayElements(env, freq, NULL);
+    jfloat *p = (*env)->GetFloatArrayElements(env, psd, NULL);
+    spec_status st = spec_welch_psd_planar_f64(ctx, r, i, (uint64_t)n, (uint32_t)nfft, (uint32_t)hop,
+                                               (spec_window)window, (spec_psd_scaling)scaling, fs, db ? 1 : 0, f, p);
+    (*env)->ReleaseFloatArrayElements(env, psd, p, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, freq, f, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, im, i, JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, re, r, JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
 JNIEXPORT jint JNICALL JNI_FN(nativeDtype)(JNIEnv *env, jclass k, jstring datatype) {
     (void)k;
     const char *dt = (*env)->GetStringUTFChars(env, datatype, NULL);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "spec_waterfall": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u64, _i32, _i32, _dbl, _vp, _i32]),
     "spec_welch_psd": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _u32, _i32, _u32, _u32, _u32, _i32, _i32,
                               _dbl, _i32, _vp, _vp, _i32]),
+    "spec_welch_psd_planar_f64": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "spec_synth_iq": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64]),
 }
 

@@ -30,7 +30,8 @@ struct spec_ctx {
     // grow-only device scratch
     void *stage_in = nullptr;  size_t stage_in_bytes = 0;
     void *stage_out = nullptr; size_t stage_out_bytes = 0;
-    void *scratch = nullptr;   size_t scratch_bytes = 0;
+    void *scratch = nullptr;   size_t scratch_bytes = 0;   // large-N transposes, Welch slabs
+    void *scratch2 = nullptr;  size_t scratch2_bytes = 0;  // fallback Welch: power lines + accumulator
     // tuning / testing knobs (spec_set_option)
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0;
     int n_cu = 256;
@@ -166,6 +167,7 @@ void spec_destroy(spec_ctx *c) {
     (void)hipFree(c->stage_in);
     (void)hipFree(c->stage_out);
     (void)hipFree(c->scratch);
+    (void)hipFree(c->scratch2);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -496,8 +498,12 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
     if (n_seg == 0 || n_psd == 0) return fail(c, SPEC_EINVAL, "n_seg and n_psd must be >= 1");
     if (!(fs > 0)) return fail(c, SPEC_EINVAL, "fs must be positive");
     if (scaling != SPEC_PSD_DENSITY && scaling != SPEC_PSD_SPECTRUM) return fail(c, SPEC_EINVAL, "bad scaling");
-    if (dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE || !plan_supported(log2n, false))
-        return fail(c, SPEC_EUNSUPPORTED, "Welch PSD: nfft = %u / cf64 not supported yet", nfft);
+    const bool f64 = dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
+    {
+        int l1 = 0, l2 = 0;
+        if (!plan_supported(log2n, f64) && !large_split(log2n, f64, &l1, &l2))
+            return fail(c, SPEC_EUNSUPPORTED, "Welch PSD: nfft = %u is not supported (2 ... 65536)", nfft);
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t bps = spec_bytes_per_sample(dt);
     const uint64_t span = ((uint64_t)(n_seg - 1) * hop + nfft) * bps;
@@ -571,28 +577,38 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
             for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
         return SPEC_OK;
     }
-    const int lpw = plan_lpw(log2n);
-    // enough workgroups to fill the chip when few PSDs are requested
-    uint32_t chunks = (n_seg + lpw - 1) / lpw;  // at most one group of LPW segments per workgroup
-    const uint32_t want = n_psd >= 2048 ? 1 : (2048 + n_psd - 1) / n_psd;
-    if (chunks > want) chunks = want;
-    a.segs_per_wg = ((n_seg + chunks - 1) / chunks + lpw - 1) / lpw * lpw;
-    a.n_chunks = (n_seg + a.segs_per_wg - 1) / a.segs_per_wg;
-    const uint32_t n_slabs = a.n_chunks * lpw;
-    st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)n_psd * n_slabs * nfft * sizeof(float));
+    // Fallback for what the packed family does not take (cf64, big-endian files, nfft < 256 or
+    // > 16384): |X|^2 lines of the spectrogram path (fp64 for cf64) summed per bin in a fixed order.
+    const spec_out_fmt pfmt = f64 ? SPEC_OUT_POW_F64 : SPEC_OUT_POW_F32;
+    const size_t esz = f64 ? 8 : 4;
+    uint64_t seg_chunk = (128ull << 20) / ((uint64_t)nfft * esz);
+    if (seg_chunk == 0) seg_chunk = 1;
+    if (seg_chunk > n_seg) seg_chunk = n_seg;
+    st = grow(c, &c->scratch2, &c->scratch2_bytes, (size_t)seg_chunk * nfft * esz + (size_t)nfft * sizeof(double));
     if (st != SPEC_OK) return st;
-    a.partial = static_cast<float *>(c->scratch);
+    double *acc = reinterpret_cast<double *>(static_cast<uint8_t *>(c->scratch2) + (size_t)seg_chunk * nfft * esz);
     float *d_out = psd_out;
     if (!out_on_device) {
         st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * sizeof(float));
         if (st != SPEC_OK) return st;
         d_out = static_cast<float *>(c->stage_out);
     }
-    hipError_t e = launch_welch_f32(a, log2n, c->stream);
-    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch launch: %s", hipGetErrorString(e));
+    st = get_window(c, log2n, f64, window, &a.win, &s1, &s2);
+    if (st != SPEC_OK) return st;
     const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
-    e = launch_welch_finalize(a.partial, n_psd, n_slabs, nfft, norm, db, d_out, c->stream);
-    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch finalize launch: %s", hipGetErrorString(e));
+    for (uint32_t b = 0; b < n_psd; ++b) {
+        HIP_TRY(c, hipMemsetAsync(acc, 0, (size_t)nfft * sizeof(double), c->stream));
+        for (uint64_t s0 = 0; s0 < n_seg; s0 += seg_chunk) {
+            const uint64_t ns = n_seg - s0 < seg_chunk ? n_seg - s0 : seg_chunk;
+            st = run_lines(c, d_in + (uint64_t)b * psd_stride_bytes + s0 * hop * bps, dt, log2n, hop, ns, window, pfmt,
+                           c->scratch2);
+            if (st != SPEC_OK) return st;
+            hipError_t e = launch_welch_accum(c->scratch2, f64, ns, nfft, acc, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch accumulate launch: %s", hipGetErrorString(e));
+        }
+        hipError_t e = launch_welch_scale(acc, nfft, norm, db, d_out + (size_t)b * nfft, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch scale launch: %s", hipGetErrorString(e));
+    }
     if (!out_on_device) {
         HIP_TRY(c, hipMemcpyAsync(psd_out, d_out, (size_t)n_psd * nfft * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -602,6 +618,27 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
     if (freq_out)  // AnalysisDialogController.java:324-328 adds centerFreq to this axis
         for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
     return SPEC_OK;
+}
+
+// Exact shape of the call at AnalysisDialogController.java:308-312:
+//   PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft)
+// with data[0] = I, data[1] = Q (planar doubles, the output of the down-converter).
+spec_status spec_welch_psd_planar_f64(spec_ctx *c, const double *re, const double *im, uint64_t n_samples,
+                                      uint32_t nfft, uint32_t hop, spec_window window, spec_psd_scaling scaling,
+                                      double fs, int db, double *freq_out, float *psd_out) {
+    if (!c) return SPEC_EINVAL;
+    if (!re || !im || !psd_out) return fail(c, SPEC_EINVAL, "null buffer");
+    if (nfft == 0 || (nfft & (nfft - 1)) != 0) return fail(c, SPEC_EINVAL, "nfft = %u is not a power of two", nfft);
+    if (hop == 0) return fail(c, SPEC_EINVAL, "hop must be >= 1");
+    if (n_samples < nfft) return fail(c, SPEC_ERANGE, "signal of %llu samples is shorter than nfft = %u",
+                                      (unsigned long long)n_samples, nfft);
+    const uint64_t n_seg = (n_samples - nfft) / hop + 1, used = (n_seg - 1) * hop + nfft;
+    if (n_seg > 0xFFFFFFFFull) return fail(c, SPEC_EINVAL, "too many segments");
+    std::vector<double> inter;
+    try { inter.resize(2 * used); } catch (...) { return fail(c, SPEC_ENOMEM, "out of host memory"); }
+    for (uint64_t i = 0; i < used; ++i) { inter[2 * i] = re[i]; inter[2 * i + 1] = im[i]; }
+    return spec_welch_psd(c, inter.data(), 0, used * 16, 0, 0, 1, SPEC_DT_CF64_LE /* host doubles */, nfft, hop,
+                          (uint32_t)n_seg, window, scaling, fs, db, freq_out, psd_out, 0);
 }
 
 spec_status spec_synth_iq(spec_ctx *c, void *dev_out, spec_dtype dt, uint64_t seed, uint64_t first_sample,

@@ -121,6 +121,11 @@ template <int LOG2N> struct Plan;
         static constexpr int NPASS = NP;                         \
         static constexpr int radix[4] = {__VA_ARGS__};           \
     };
+SPEC_PLAN(1, 2, 1, 2, 1, 1, 1)
+SPEC_PLAN(2, 4, 1, 4, 1, 1, 1)
+SPEC_PLAN(3, 8, 1, 8, 1, 1, 1)
+SPEC_PLAN(4, 16, 1, 16, 1, 1, 1)
+SPEC_PLAN(5, 16, 2, 16, 2, 1, 1)
 SPEC_PLAN(6, 8, 2, 8, 8, 1, 1)
 SPEC_PLAN(7, 16, 2, 16, 8, 1, 1)
 SPEC_PLAN(8, 16, 2, 16, 16, 1, 1)

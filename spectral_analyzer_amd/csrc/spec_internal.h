@@ -26,16 +26,16 @@ struct WfArgs {
     uint32_t lines_per_wg;  // contiguous lines handled by one workgroup (multiple of LPW)
 };
 
-// Arguments of one Welch partial-sum launch: PSD b, chunk c accumulates
-// segments [c*segs_per_wg, ...) into partial[(b*n_chunks + c)*LPW + q][N].
+// Arguments of one Welch partial-sum launch (spec_v2.h, MODE 1): every sub-line sums |X|^2
+// over its run of segments into one slab of partial[psd][slab][N].
 struct WelchArgs {
     const uint8_t *iq;          // first byte of segment 0 of PSD 0
     uint64_t psd_stride_bytes;
-    uint32_t n_psd, n_seg, n_chunks, segs_per_wg;
+    uint32_t n_psd, n_seg;
     uint32_t hop, bps;
     int kind, be;
     const void *tw, *win;
-    float *partial;             // [n_psd][n_chunks*LPW][N] unshifted power sums (fp32)
+    float *partial;             // [n_psd][slabs][N] unshifted power sums (fp32)
 };
 
 int plan_lpw(int log2n);  // lines a workgroup transforms concurrently
@@ -43,7 +43,6 @@ bool plan_supported(int log2n, bool f64);
 
 hipError_t launch_spectro_f32(const WfArgs &a, int log2n, hipStream_t s);
 hipError_t launch_spectro_f64(const WfArgs &a, int log2n, hipStream_t s);
-hipError_t launch_welch_f32(const WelchArgs &a, int log2n, hipStream_t s);
 
 // large-N four-step path (spec_k_large.hip): w.tw is the W_N table, tw1/tw2 the
 // W_N1 / W_N2 tables of the split, scratch holds n_lines * N complex values
@@ -61,6 +60,10 @@ hipError_t launch_v2_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t
 hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);
 hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs,
                                  uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);
+// fallback Welch: acc[k] += sum over n lines of fftshifted power lines (float or double);
+// then scale / dB into psd_out
+hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint32_t nfft, double *acc, hipStream_t s);
+hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);
 hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t first_sample,
                         uint64_t n_samples, hipStream_t s);
 

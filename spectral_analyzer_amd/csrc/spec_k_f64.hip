@@ -6,6 +6,11 @@ namespace specgpu {
 
 hipError_t launch_spectro_f64(const WfArgs &a, int log2n, hipStream_t s) {
     switch (log2n) {
+    case 1: return launch_spectro_one<double, 1>(a, s);
+    case 2: return launch_spectro_one<double, 2>(a, s);
+    case 3: return launch_spectro_one<double, 3>(a, s);
+    case 4: return launch_spectro_one<double, 4>(a, s);
+    case 5: return launch_spectro_one<double, 5>(a, s);
     case 6: return launch_spectro_one<double, 6>(a, s);
     case 7: return launch_spectro_one<double, 7>(a, s);
     case 8: return launch_spectro_one<double, 8>(a, s);

@@ -10,7 +10,7 @@ bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, u
     if (kind != K_CF32 && kind != K_CI16 && kind != K_CU8 && kind != K_CI8) return false;
     if (out_fmt != OUT_DB20_F32 && out_fmt != OUT_POW_F32) return false;
     // 32-bit offsets inside a workgroup's span
-    return n_lines < (1ull << 31) && (uint64_t)hop * 16 < (1ull << 24);
+    return n_lines < (1ull << 31) && hop <= (8u << log2n);  // span of a workgroup stays far below 4 GiB
 }
 
 int v2_lpw(int log2n) {

@@ -1,6 +1,6 @@
-// spec_kernels.h -- the generic spectrogram / Welch kernels (any nfft in the
-// plan table, any datatype), instantiated per precision in spec_k_f32.hip and
-// spec_k_f64.hip.  The tuned 4096-point kernels live in spec_k_tuned.hip.
+// spec_kernels.h -- the generic spectrogram kernel (any nfft in the plan table, any
+// datatype, either byte order, fp32 or fp64), instantiated per precision in
+// spec_k_f32.hip and spec_k_f64.hip.  The packed-fp32 product path is spec_v2.h.
 #pragma once
 #include "spec_fft.h"
 #include "spec_internal.h"
@@ -74,45 +74,6 @@ __global__ __launch_bounds__(Plan<LOG2N>::WG) void spectro_kernel(const WfArgs a
     }
 }
 
-// Welch partial sums: each sub-line accumulates |X|^2 of its segments in
-// registers and writes one fp32 slab; launch_welch_finalize reduces the slabs.
-template <typename R, int LOG2N>
-__global__ __launch_bounds__(Plan<LOG2N>::WG) void welch_kernel(const WelchArgs a) {
-    using PL = Plan<LOG2N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, t = tid % PL::T, q = tid / PL::T;
-    cx<R> *lds = reinterpret_cast<cx<R> *>(smem) + (size_t)q * PL::N;
-    const cx<R> *__restrict__ tw = static_cast<const cx<R> *>(a.tw);
-    const R *__restrict__ win = static_cast<const R *>(a.win);
-    const uint32_t psd = blockIdx.x / a.n_chunks, chunk = blockIdx.x % a.n_chunks;
-
-    R w[PL::E], acc[PL::E];
-#pragma unroll
-    for (int m = 0; m < PL::E; ++m) { w[m] = win ? win[t + m * PL::T] : (R)1; acc[m] = 0; }
-    const uint32_t first = chunk * a.segs_per_wg;
-    uint32_t last = first + a.segs_per_wg;
-    if (last > a.n_seg) last = a.n_seg;
-    const uint8_t *base = a.iq + (uint64_t)psd * a.psd_stride_bytes;
-    const uint64_t seg_bytes = (uint64_t)a.hop * a.bps;
-
-    for (uint32_t g = first; g < last; g += PL::LPW) {
-        const uint32_t seg = g + q;
-        const bool active = seg < last;
-        cx<R> v[PL::E];
-        load_line<R, LOG2N>(v, base + (uint64_t)(active ? seg : last - 1) * seg_bytes, t, a.bps, a.kind, a.be != 0);
-#pragma unroll
-        for (int m = 0; m < PL::E; ++m) { v[m].x *= w[m]; v[m].y *= w[m]; }
-        fft_line<R, LOG2N>(v, t, lds, tw);
-        if (active) {
-#pragma unroll
-            for (int m = 0; m < PL::E; ++m) acc[m] += v[m].x * v[m].x + v[m].y * v[m].y;
-        }
-    }
-    float *slab = a.partial + ((uint64_t)blockIdx.x * PL::LPW + q) * PL::N;
-#pragma unroll
-    for (int m = 0; m < PL::E; ++m) slab[t + m * PL::T] = (float)acc[m];
-}
-
 template <typename R, int LOG2N> hipError_t launch_spectro_one(const WfArgs &a, hipStream_t s) {
     using PL = Plan<LOG2N>;
     const size_t lds = (size_t)PL::LPW * PL::N * sizeof(cx<R>);
@@ -123,18 +84,6 @@ template <typename R, int LOG2N> hipError_t launch_spectro_one(const WfArgs &a, 
     }
     const uint64_t n_wg = (a.n_lines + a.lines_per_wg - 1) / a.lines_per_wg;
     hipLaunchKernelGGL((spectro_kernel<R, LOG2N>), dim3((unsigned)n_wg), dim3(PL::WG), lds, s, a);
-    return hipGetLastError();
-}
-
-template <typename R, int LOG2N> hipError_t launch_welch_one(const WelchArgs &a, hipStream_t s) {
-    using PL = Plan<LOG2N>;
-    const size_t lds = (size_t)PL::LPW * PL::N * sizeof(cx<R>);
-    if (lds > 64 * 1024) {  // per device, so set on every launch of the big-LDS plans
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&welch_kernel<R, LOG2N>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((welch_kernel<R, LOG2N>), dim3(a.n_psd * a.n_chunks), dim3(PL::WG), lds, s, a);
     return hipGetLastError();
 }
 

@@ -41,6 +41,34 @@ hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t 
     return hipGetLastError();
 }
 
+// ---- fallback Welch (any datatype / size the packed family does not take): mean of power lines
+template <typename T>
+__global__ void welch_accum_kernel(const T *__restrict__ lines, uint64_t n, uint32_t nfft, double *__restrict__ acc) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfft) return;
+    double a = acc[k];
+    for (uint64_t l = 0; l < n; ++l) a += (double)lines[l * nfft + k];  // fixed order: reproducible
+    acc[k] = a;
+}
+__global__ void welch_scale_kernel(const double *__restrict__ acc, uint32_t nfft, double norm, int db,
+                                   float *__restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfft) return;
+    const double v = acc[k] * norm;
+    out[k] = db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+}
+hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint32_t nfft, double *acc, hipStream_t s) {
+    if (lines_f64) hipLaunchKernelGGL(welch_accum_kernel<double>, dim3((nfft + 63) / 64), dim3(64), 0, s,
+                                      static_cast<const double *>(lines), n, nfft, acc);
+    else hipLaunchKernelGGL(welch_accum_kernel<float>, dim3((nfft + 63) / 64), dim3(64), 0, s,
+                            static_cast<const float *>(lines), n, nfft, acc);
+    return hipGetLastError();
+}
+hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s) {
+    hipLaunchKernelGGL(welch_scale_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, acc, nfft, norm, db, psd_out);
+    return hipGetLastError();
+}
+
 // ---- synthetic IQ: two tones + Gaussian noise, counter based ----------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

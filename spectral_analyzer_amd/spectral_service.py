@@ -202,6 +202,23 @@ class SpectralService:
             int(on_dev)))
         return freq, psd
 
+    def calculate_psd_welch(self, data, fs: float, nfft: int, hop: Optional[int] = None,
+                            window: int = L.WIN_HANN, scaling: int = L.PSD_DENSITY, db: bool = False):
+        """The call at ADC:308-312, ``PowerSpectralDensity.calculatePsdWelch(data, fs, nfft)``:
+        ``data`` is ``double[2][N]`` (row 0 = I, row 1 = Q); returns ``[freq, psd]`` like the
+        reference's two rows.  Window / overlap / scaling are explicit because JDSP's are not
+        known (defaults: Hann, 50 %, density, linear)."""
+        d = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
+        if d.ndim != 2 or d.shape[0] != 2:
+            raise ValueError("data must be double[2][N]")
+        hop = int(nfft // 2 if hop is None else hop)
+        freq = np.empty(max(int(nfft), 0), dtype=np.float64)
+        psd = np.empty(max(int(nfft), 0), dtype=np.float32)
+        self._check(self._lib.spec_welch_psd_planar_f64(
+            self._ctx, d[0].ctypes.data, d[1].ctypes.data, d.shape[1], int(nfft) & 0xFFFFFFFF, hop, window,
+            scaling, float(fs), int(db), freq.ctypes.data, psd.ctypes.data))
+        return np.stack([freq, psd.astype(np.float64)])
+
     # -- synthetic recording (bench / tests) --------------------------------
     def synth_iq(self, datatype: str, seed: int, first_sample: int, n_samples: int, out=None):
         """Counter-based synthetic IQ generated on the device (uint8 tensor)."""

@@ -282,3 +282,49 @@ def test_compute_magnitudes_at_ui_maximum(svc, oracle):
     check_fp64(got[None, :], oracle.compute_magnitudes(iq, 0, 65536, "ci16_le")[None, :])
     with pytest.raises(NotImplementedError):
         svc.compute_magnitudes(np.zeros(8 << 17, np.uint8), 0, 1 << 17, "cf32_le")
+
+
+# ---- the whole power-of-two range of the reference service (commons-math3 takes any 2^k) ----------
+@pytest.mark.parametrize("nfft", [2, 4, 8, 16, 32])
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_be", "cu8", "cf64_le"])
+def test_tiny_nfft(svc, oracle, datatype, nfft):
+    n_lines = 37
+    iq = oracle.synth_iq(datatype, nfft, 0, n_lines * nfft)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, nfft, n_lines)
+    check_fp32(svc.compute_waterfall(iq, 0, nfft, datatype, n_lines), ref, max(nfft, 4))
+    one = svc.compute_magnitudes(iq, 0, nfft, datatype)
+    check_fp64(one[None, :], oracle.compute_magnitudes(iq, 0, nfft, datatype, cf64_decode=True)[None, :])
+
+
+# ---- Welch for everything the fused path does not take (cf64, big endian, very small / large nfft) --
+@pytest.mark.parametrize("datatype,nfft,hop,n_seg", [("cf64_le", 1024, 512, 9), ("cf64_be", 16384, 4096, 6),
+                                                     ("ci16_be", 2048, 1024, 7), ("cf32_le", 64, 16, 40),
+                                                     ("cf32_le", 32768, 8192, 5), ("cf64_le", 65536, 32768, 3)])
+def test_welch_fallback_paths(svc, oracle, datatype, nfft, hop, n_seg):
+    fs = 1e6
+    iq = oracle.synth_iq(datatype, 8, 0, (n_seg - 1) * hop + nfft)
+    f_ref, p_ref = oracle.welch_psd(iq, 0, datatype, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY, fs)
+    f, p = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg)
+    assert np.array_equal(f, f_ref)
+    tol = 1e-6 if datatype.startswith("cf64") else 5e-6        # the result itself is float32
+    assert np.abs(p[0] - p_ref).max() <= tol * p_ref.max()
+
+
+def test_calculate_psd_welch_call_shape(svc, oracle):
+    # AnalysisDialogController.java:303-313: data = double[2][N], nfft = 8192 (or the length if shorter)
+    import scipy.signal
+    rng = np.random.default_rng(5)
+    n, fs, nfft = 50000, 250e3, 8192
+    x = rng.normal(size=n) + 1j * rng.normal(size=n) + 3 * np.exp(2j * np.pi * 0.11 * np.arange(n))
+    data = np.stack([x.real, x.imag])
+    out = svc.calculate_psd_welch(data, fs, nfft)
+    assert out.shape == (2, nfft)
+    f_ref, p_ref = scipy.signal.welch(x, fs, window="hann", nperseg=nfft, noverlap=nfft // 2, nfft=nfft,
+                                      detrend=False, return_onesided=False, scaling="density")
+    assert np.allclose(out[0], np.fft.fftshift(f_ref))
+    assert np.abs(out[1] - np.fft.fftshift(p_ref)).max() <= 1e-6 * p_ref.max()
+    assert int(np.argmax(out[1])) == int(round(0.11 * nfft)) + nfft // 2
+    with pytest.raises(IndexError):                      # shorter than nfft: the caller picks nfft (ADC:303-307)
+        svc.calculate_psd_welch(data[:, :100], fs, nfft)
+    with pytest.raises(ValueError):
+        svc.calculate_psd_welch(data, fs, 1000)
