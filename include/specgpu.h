@@ -154,6 +154,31 @@ spec_status spec_waterfall(spec_ctx *ctx, const void *iq, int iq_on_device, uint
                            uint64_t n_lines, spec_window window, spec_out_fmt out_fmt,
                            double eof_fill, void *out, int out_on_device);
 
+/* ---- rendering (SURVEY 8f "next" #1) ------------------------------------- */
+
+typedef enum {
+    SPEC_CMAP_GRAYSCALE = 0,  /* "Grayscale"  MainController.java:939-941 */
+    SPEC_CMAP_HEATMAP = 1     /* "Heatmap"    MainController.java:943-953 */
+} spec_colormap;
+
+/* Replacement for MainController.renderSpectrogram (MainController.java:1261-1291) with
+ * getColorForMagnitude (MainController.java:926-957): `tile` is width x nfft fp32 dB lines
+ * (SPEC_OUT_DB20_F32, one line per canvas column); pixel (x, height-1-f) shows bin
+ * (int)((double)f / height * nfft) minus 10 log10(fs/nfft) + 20 log10(nfft) (MC:1273-1274),
+ * mapped through [min_db, max_db] and the colour map.  Output: height x width pixels, 4 bytes
+ * B,G,R,A each (= JavaFX IntArgb little endian), row 0 on top. */
+spec_status spec_render_spectrogram(spec_ctx *ctx, const float *tile, int tile_on_device, uint32_t width,
+                                    uint32_t nfft, uint32_t height, double fs, double min_db, double max_db,
+                                    spec_colormap colormap, void *bgra_out, int out_on_device);
+
+/* spec_waterfall (DB20_F32, fftshifted) followed by spec_render_spectrogram without the dB
+ * tile ever leaving the device: one call per redraw of MainController.updateDisplay()
+ * (MainController.java:962-1049); n_lines = canvas width. */
+spec_status spec_waterfall_render(spec_ctx *ctx, const void *iq, int iq_on_device, uint64_t n_bytes,
+                                  uint64_t start_byte, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                                  uint32_t n_lines, spec_window window, uint32_t height, double fs, double min_db,
+                                  double max_db, spec_colormap colormap, void *bgra_out, int out_on_device);
+
 /* ---- Welch PSD ----------------------------------------------------------- */
 
 /* Replacement for the call

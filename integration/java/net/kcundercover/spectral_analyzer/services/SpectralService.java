@@ -77,6 +77,23 @@ public class SpectralService implements AutoCloseable {
     }
 
     /**
+     * One redraw in one device call: the {@code canvasW} lines of {@code MainController.updateDisplay()}
+     * followed by {@code renderSpectrogram} / {@code getColorForMagnitude}.  Returns {@code height * width}
+     * IntArgb pixels, row 0 on top, for
+     * {@code PixelWriter.setPixels(0, 0, width, height, PixelFormat.getIntArgbInstance(), argb, 0, width)}.
+     *
+     * @param colorMap 0 = "Grayscale", 1 = "Heatmap"
+     */
+    public int[] renderWaterfall(ByteBuffer buffer, long startByte, int nfft, int hop, String datatype,
+                                 int width, int height, double sampleRate, double minDecibel,
+                                 double maxDecibel, int colorMap) {
+        int[] argb = new int[Math.multiplyExact(width, height)];
+        nativeWaterfallRender(handle, buffer, startByte, nativeDtype(datatype), nfft, hop, width, WINDOW_RECT,
+                height, sampleRate, minDecibel, maxDecibel, colorMap, argb);
+        return argb;
+    }
+
+    /**
      * Same argument shape as {@code PowerSpectralDensity.calculatePsdWelch(data, fs, nfft)} in the
      * PSD dialog: {@code data[0]} = I, {@code data[1]} = Q.  Hann window, 50 % overlap, density
      * scaling, linear power; returns {frequency axis, psd}.
@@ -107,6 +124,10 @@ public class SpectralService implements AutoCloseable {
     private static native void nativeWelch(long handle, ByteBuffer buffer, long startByte, int dtype, int nfft,
                                            int hop, int segments, int window, int scaling, double sampleRate,
                                            boolean decibel, double[] freq, float[] psd);
+    private static native void nativeWaterfallRender(long handle, ByteBuffer buffer, long startByte, int dtype,
+                                                     int nfft, int hop, int width, int window, int height,
+                                                     double sampleRate, double minDb, double maxDb, int colorMap,
+                                                     int[] argb);
     private static native void nativeWelchPlanar(long handle, double[] re, double[] im, int nfft, int hop,
                                                  int window, int scaling, double sampleRate, boolean decibel,
                                                  double[] freq, float[] psd);

@@ -103,6 +103,29 @@ JNIEXPORT void JNICALL JNI_FN(nativeWelch)(JNIEnv *env, jclass k, jlong h, jobje
     if (st != SPEC_OK) throw_status(env, ctx, st);
 }
 
+/* one redraw: MainController.updateDisplay() slice loop + renderSpectrogram (MC:962-1049, MC:1261-1291);
+ * argb receives height*width IntArgb pixels (B,G,R,A bytes = little-endian int), ready for
+ * PixelWriter.setPixels(0, 0, w, h, PixelFormat.getIntArgbInstance(), argb, 0, w) */
+JNIEXPORT void JNICALL JNI_FN(nativeWaterfallRender)(JNIEnv *env, jclass k, jlong h, jobject buffer, jlong startByte,
+                                                      jint dtype, jint nfft, jint hop, jint width, jint window,
+                                                      jint height, jdouble fs, jdouble minDb, jdouble maxDb,
+                                                      jint colormap, jintArray argb) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    void *base = (*env)->GetDirectBufferAddress(env, buffer);
+    jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
+    if (!base || cap < 0 || (jlong)(*env)->GetArrayLength(env, argb) < (jlong)width * height) {
+        throw_status(env, ctx, SPEC_EINVAL);
+        return;
+    }
+    jint *px = (*env)->GetIntArrayElements(env, argb, NULL);
+    spec_status st = spec_waterfall_render(ctx, base, 0, (uint64_t)cap, (uint64_t)startByte, (spec_dtype)dtype,
+                                           (uint32_t)nfft, (uint32_t)hop, (uint32_t)width, (spec_window)window,
+                                           (uint32_t)height, fs, minDb, maxDb, (spec_colormap)colormap, px, 0);
+    (*env)->ReleaseIntArrayElements(env, argb, px, st == SPEC_OK ? 0 : JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
 /* PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft) -- ADC:308-312 */
 JNIEXPORT void JNICALL JNI_FN(nativeWelchPlanar)(JNIEnv *env, jclass k, jlong h, jdoubleArray re, jdoubleArray im,
                                                   jint nfft, jint hop, jint window, jint scaling, jdouble fs,

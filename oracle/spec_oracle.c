@@ -298,6 +298,40 @@ double so_display_conversion(double fs, uint32_t nfft) {
     return 10 * log10(fs / nfft) + 20 * log10((double)nfft);
 }
 
+/* ---------------- renderSpectrogram (MC:1261-1291, MC:926-957) ---------------- */
+static uint8_t chan8(float c) { return (uint8_t)floor((double)c * 255.0 + 0.5); } /* Math.round */
+
+void so_render_spectrogram(const double *waterfall, uint32_t width, uint32_t nfft, uint32_t height,
+                           double fs, double min_db, double max_db, int colormap, uint8_t *out) {
+    const double conversion = so_display_conversion(fs, nfft);                 /* MC:1273-1274 */
+    for (uint32_t t = 0; t < width; t++) {
+        for (uint32_t f = 0; f < height; f++) {
+            const int bin = (int)((double)f / height * nfft);                  /* MC:1280 */
+            const double db = waterfall[(size_t)t * nfft + bin] - conversion;  /* MC:1283 */
+            double n = (db - min_db) / (max_db - min_db);                      /* MC:929 */
+            n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);                           /* MC:930 */
+            float r, g, b;
+            if (colormap == 1) {                                               /* MC:943-953 Heatmap */
+                if (n < 0.2) { r = g = b = 0.0f; }
+                else if (n < 0.5) {                                            /* BLUE -> RED */
+                    const double tt = (n - 0.2) / 0.3;
+                    if (tt <= 0.0) { r = 0; g = 0; b = 1; } else if (tt >= 1.0) { r = 1; g = 0; b = 0; }
+                    else { const float ft = (float)tt; r = 0.0f + (1.0f - 0.0f) * ft; g = 0.0f; b = 1.0f + (0.0f - 1.0f) * ft; }
+                } else {                                                       /* RED -> YELLOW */
+                    const double tt = (n - 0.5) / 0.5;
+                    if (tt <= 0.0) { r = 1; g = 0; b = 0; } else if (tt >= 1.0) { r = 1; g = 1; b = 0; }
+                    else { const float ft = (float)tt; r = 1.0f; g = 0.0f + (1.0f - 0.0f) * ft; b = 0.0f; }
+                }
+            } else {                                                           /* MC:939-941 Grayscale */
+                if (n <= 0.0) r = 0.0f; else if (n >= 1.0) r = 1.0f; else r = 0.0f + (1.0f - 0.0f) * (float)n;
+                g = b = r;
+            }
+            uint8_t *px = out + ((size_t)(height - 1 - f) * width + t) * 4;    /* MC:1288 */
+            px[0] = chan8(b); px[1] = chan8(g); px[2] = chan8(r); px[3] = 255;
+        }
+    }
+}
+
 /* ---------------- synthetic IQ ---------------- */
 static uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

@@ -102,6 +102,15 @@ int so_welch_psd(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
  * mapping: 10 log10(fs/N) + 20 log10(N). */
 double so_display_conversion(double fs, uint32_t nfft);
 
+/* MainController.java:1261-1291 renderSpectrogram + MainController.java:926-957
+ * getColorForMagnitude, restated: waterfall is [width][nfft] dB lines; pixel (t, height-1-f)
+ * takes bin (int)((double)f / height * nfft), minus so_display_conversion, normalised to
+ * [min_db, max_db], through colour map 0 = "Grayscale" / 1 = "Heatmap" (javafx Color.interpolate
+ * in float, 8-bit channel = round(c * 255) as PixelWriter.setColor does -- JavaFX is not in the
+ * reference tree: that rounding is the published behaviour, unpinned).  out: height x width BGRA. */
+void so_render_spectrogram(const double *waterfall, uint32_t width, uint32_t nfft, uint32_t height,
+                           double fs, double min_db, double max_db, int colormap, uint8_t *bgra_out);
+
 /* SURVEY 8(d) synthetic IQ (counter based, any shard can generate its own
  * span): writes n_samples IQ pairs starting at absolute sample first_sample in
  * the byte layout of `datatype` (honours _be). */

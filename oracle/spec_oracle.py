@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
                                    dp, dp]
         L.so_display_conversion.argtypes = [C.c_double, C.c_uint32]
         L.so_display_conversion.restype = C.c_double
+        L.so_render_spectrogram.argtypes = [dp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                            C.c_double, C.c_int, u8p]
         L.so_synth_iq.argtypes = [u8p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64]
         L.so_time_waterfall.argtypes = [u8p, C.c_uint64, C.c_char_p, C.c_uint32, C.c_uint32,
                                         C.c_uint64, C.c_int, C.c_int, dp]
@@ -137,6 +139,16 @@ def welch_psd(buf, start_byte: int, datatype: str, nfft: int, hop: int, n_seg: i
 
 def display_conversion(fs: float, nfft: int) -> float:
     return float(lib().so_display_conversion(fs, nfft))
+
+
+def render_spectrogram(waterfall: np.ndarray, height: int, fs: float, min_db: float = -100.0,
+                       max_db: float = 0.0, colormap: int = 0) -> np.ndarray:
+    """MC:1261-1291 + MC:926-957; waterfall [width, nfft] (dB) -> uint8 [height, width, 4] BGRA."""
+    w = np.ascontiguousarray(waterfall, dtype=np.float64)
+    out = np.empty((height, w.shape[0], 4), dtype=np.uint8)
+    lib().so_render_spectrogram(w.ctypes.data, w.shape[0], w.shape[1], height, fs, min_db, max_db, colormap,
+                                out.ctypes.data)
+    return out
 
 
 def synth_iq(datatype: str, seed: int, first_sample: int, n_samples: int) -> np.ndarray:

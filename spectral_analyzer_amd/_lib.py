@@ -21,6 +21,7 @@ SPEC_OK, SPEC_EINVAL, SPEC_ERANGE, SPEC_EDEVICE, SPEC_ENOMEM, SPEC_EUNSUPPORTED 
 WIN_RECT, WIN_HANN = 0, 1
 OUT_DB20_F32, OUT_POW_F32, OUT_DB20_F64, OUT_POW_F64 = range(4)
 PSD_DENSITY, PSD_SPECTRUM = 0, 1
+CMAP_GRAYSCALE, CMAP_HEATMAP = 0, 1
 FLAG_REF_CF64_ZERO = 0x1
 FLAG_NULL_STREAM = 0x2
 
@@ -41,6 +42,9 @@ SIGNATURES = {
     "spec_waterfall": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u64, _i32, _i32, _dbl, _vp, _i32]),
     "spec_welch_psd": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _u32, _i32, _u32, _u32, _u32, _i32, _i32,
                               _dbl, _i32, _vp, _vp, _i32]),
+    "spec_render_spectrogram": (_i32, [_vp, _vp, _i32, _u32, _u32, _u32, _dbl, _dbl, _dbl, _i32, _vp, _i32]),
+    "spec_waterfall_render": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u32, _i32, _u32, _dbl, _dbl,
+                                     _dbl, _i32, _vp, _i32]),
     "spec_welch_psd_planar_f64": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "spec_synth_iq": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64]),
 }

@@ -641,6 +641,59 @@ spec_status spec_welch_psd_planar_f64(spec_ctx *c, const double *re, const doubl
                           (uint32_t)n_seg, window, scaling, fs, db, freq_out, psd_out, 0);
 }
 
+spec_status spec_render_spectrogram(spec_ctx *c, const float *tile, int tile_on_device, uint32_t width,
+                                    uint32_t nfft, uint32_t height, double fs, double min_db, double max_db,
+                                    spec_colormap colormap, void *bgra_out, int out_on_device) {
+    if (!c) return SPEC_EINVAL;
+    if (!tile || !bgra_out) return fail(c, SPEC_EINVAL, "null buffer");
+    if (nfft == 0 || !(fs > 0)) return fail(c, SPEC_EINVAL, "nfft and fs must be positive");
+    if (colormap != SPEC_CMAP_GRAYSCALE && colormap != SPEC_CMAP_HEATMAP) return fail(c, SPEC_EINVAL, "bad colormap");
+    if (width == 0 || height == 0) return SPEC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)width * nfft * sizeof(float), out_bytes = (size_t)width * height * 4;
+    const float *d_tile = tile;
+    if (!tile_on_device) {
+        spec_status st = grow(c, &c->stage_in, &c->stage_in_bytes, in_bytes);
+        if (st != SPEC_OK) return st;
+        HIP_TRY(c, hipMemcpyAsync(c->stage_in, tile, in_bytes, hipMemcpyHostToDevice, c->stream));
+        d_tile = static_cast<const float *>(c->stage_in);
+    }
+    void *d_out = bgra_out;
+    if (!out_on_device) {
+        spec_status st = grow(c, &c->stage_out, &c->stage_out_bytes, out_bytes);
+        if (st != SPEC_OK) return st;
+        d_out = c->stage_out;
+    }
+    const double conversion = 10 * std::log10(fs / nfft) + 20 * std::log10((double)nfft);  // MC:1273-1274
+    hipError_t e = launch_render(d_tile, width, nfft, height, conversion, min_db, max_db, (int)colormap, d_out, c->stream);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "render launch: %s", hipGetErrorString(e));
+    if (!out_on_device) {
+        HIP_TRY(c, hipMemcpyAsync(bgra_out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if (!tile_on_device) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return SPEC_OK;
+}
+
+spec_status spec_waterfall_render(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes,
+                                  uint64_t start_byte, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                                  uint32_t n_lines, spec_window window, uint32_t height, double fs, double min_db,
+                                  double max_db, spec_colormap colormap, void *bgra_out, int out_on_device) {
+    if (!c) return SPEC_EINVAL;
+    if (!bgra_out) return fail(c, SPEC_EINVAL, "null buffer");
+    if (n_lines == 0 || height == 0) return SPEC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // dB tile lives in the context's scratch2 and never crosses PCIe
+    spec_status st = grow(c, &c->scratch2, &c->scratch2_bytes, (size_t)n_lines * nfft * sizeof(float));
+    if (st != SPEC_OK) return st;
+    st = spec_waterfall(c, iq, iq_on_device, n_bytes, start_byte, dt, nfft, hop, n_lines, window, SPEC_OUT_DB20_F32,
+                        -150.0, c->scratch2, 1);
+    if (st != SPEC_OK) return st;
+    return spec_render_spectrogram(c, static_cast<const float *>(c->scratch2), 1, n_lines, nfft, height, fs, min_db,
+                                   max_db, colormap, bgra_out, out_on_device);
+}
+
 spec_status spec_synth_iq(spec_ctx *c, void *dev_out, spec_dtype dt, uint64_t seed, uint64_t first_sample,
                           uint64_t n_samples) {
     if (!c) return SPEC_EINVAL;

@@ -64,6 +64,8 @@ hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t 
 // then scale / dB into psd_out
 hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint32_t nfft, double *acc, hipStream_t s);
 hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);
+hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
+                         double min_db, double max_db, int colormap, void *bgra, hipStream_t s);
 hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t first_sample,
                         uint64_t n_samples, hipStream_t s);
 

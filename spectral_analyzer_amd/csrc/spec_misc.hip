@@ -69,6 +69,48 @@ hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int
     return hipGetLastError();
 }
 
+// ---- renderSpectrogram + getColorForMagnitude (MC:1261-1291, MC:926-957): dB tile -> BGRA8 ----
+// One thread per pixel, x (time) fastest so the image stores coalesce.  The arithmetic follows the
+// Java expressions operation by operation (double for the bin / normalisation, float for
+// Color.interpolate, round-half-up to 8 bits); the _rn intrinsics keep hipcc from fusing them.
+__global__ void render_kernel(const float *__restrict__ tile, uint32_t width, uint32_t nfft, uint32_t height,
+                              double conversion, double min_db, double max_db, int colormap,
+                              uchar4 *__restrict__ out) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width) return;
+    const uint32_t f = height - 1 - y;                                             // MC:1288
+    const int bin = (int)__dmul_rn(__ddiv_rn((double)f, (double)height), (double)nfft);  // MC:1280
+    const double db = __dsub_rn((double)tile[(uint64_t)x * nfft + bin], conversion);     // MC:1283
+    double n = __ddiv_rn(__dsub_rn(db, min_db), __dsub_rn(max_db, min_db));        // MC:929
+    n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);                                       // MC:930
+    float r, g, b;
+    if (colormap == 1) {                                                           // Heatmap MC:943-953
+        if (n < 0.2) { r = g = b = 0.0f; }
+        else if (n < 0.5) {
+            const double tt = __ddiv_rn(__dsub_rn(n, 0.2), 0.3);
+            if (tt <= 0.0) { r = 0; g = 0; b = 1; } else if (tt >= 1.0) { r = 1; g = 0; b = 0; }
+            else { const float ft = (float)tt; r = ft; g = 0.0f; b = __fadd_rn(1.0f, __fmul_rn(-1.0f, ft)); }
+        } else {
+            const double tt = __ddiv_rn(__dsub_rn(n, 0.5), 0.5);
+            if (tt <= 0.0) { r = 1; g = 0; b = 0; } else if (tt >= 1.0) { r = 1; g = 1; b = 0; }
+            else { r = 1.0f; g = (float)tt; b = 0.0f; }
+        }
+    } else {                                                                       // Grayscale MC:939-941
+        r = n <= 0.0 ? 0.0f : (n >= 1.0 ? 1.0f : (float)n);
+        g = b = r;
+    }
+    auto ch = [](float c) { return (unsigned char)floor(__dadd_rn(__dmul_rn((double)c, 255.0), 0.5)); };
+    out[(uint64_t)y * width + x] = make_uchar4(ch(b), ch(g), ch(r), 255);         // BGRA
+}
+
+hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
+                         double min_db, double max_db, int colormap, void *bgra, hipStream_t s) {
+    if (width == 0 || height == 0) return hipSuccess;
+    hipLaunchKernelGGL(render_kernel, dim3((width + 255) / 256, height), dim3(256), 0, s, tile, width, nfft, height,
+                       conversion, min_db, max_db, colormap, static_cast<uchar4 *>(bgra));
+    return hipGetLastError();
+}
+
 // ---- synthetic IQ: two tones + Gaussian noise, counter based ----------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ULL;

@@ -163,6 +163,40 @@ class SpectralService:
             window, out_fmt, float(eof_fill), res.ctypes.data, 0))
         return res
 
+    # -- MainController.renderSpectrogram (MC:1261-1291) + getColorForMagnitude (MC:926-957) ----
+    def render_spectrogram(self, tile, height: int, fs: float, min_db: float = -100.0, max_db: float = 0.0,
+                           colormap: int = L.CMAP_GRAYSCALE):
+        """dB tile ``[width, nfft]`` (numpy float32 or CUDA tensor) -> BGRA8 image ``[height, width, 4]``."""
+        if _is_torch(tile):
+            import torch
+            if not tile.is_cuda or tile.dtype != torch.float32 or not tile.is_contiguous():
+                raise ValueError("tile must be a contiguous CUDA float32 tensor")
+            out = torch.empty((int(height), tile.shape[0], 4), dtype=torch.uint8, device=tile.device)
+            self._check(self._lib.spec_render_spectrogram(
+                self._ctx, tile.data_ptr(), 1, tile.shape[0], tile.shape[1], int(height), float(fs), float(min_db),
+                float(max_db), colormap, out.data_ptr(), 1))
+            return out
+        t = np.ascontiguousarray(tile, dtype=np.float32)
+        out = np.empty((int(height), t.shape[0], 4), dtype=np.uint8)
+        self._check(self._lib.spec_render_spectrogram(
+            self._ctx, t.ctypes.data, 0, t.shape[0], t.shape[1], int(height), float(fs), float(min_db),
+            float(max_db), colormap, out.ctypes.data, 0))
+        return out
+
+    def waterfall_render(self, buffer, start_byte: int, nfft: int, datatype: str, width: int, height: int,
+                         fs: float, hop: Optional[int] = None, window: int = L.WIN_RECT, min_db: float = -100.0,
+                         max_db: float = 0.0, colormap: int = L.CMAP_GRAYSCALE) -> np.ndarray:
+        """One redraw of ``MainController.updateDisplay()`` (MC:962-1049): ``width`` lines from
+        ``start_byte`` rendered to a BGRA8 image; the dB tile stays on the device."""
+        b = _host_bytes(buffer)
+        hop = int(nfft if hop is None else hop)
+        out = np.empty((int(height), int(width), 4), dtype=np.uint8)
+        self._check(self._lib.spec_waterfall_render(
+            self._ctx, b.ctypes.data, 0, b.size, int(start_byte), dtype_from_sigmf(datatype), int(nfft), hop,
+            int(width), window, int(height), float(fs), float(min_db), float(max_db), colormap,
+            out.ctypes.data, 0))
+        return out
+
     def count_lines(self, n_bytes: int, start_byte: int, datatype: str, nfft: int, hop: int) -> int:
         return int(self._lib.spec_count_lines(int(n_bytes), int(start_byte), dtype_from_sigmf(datatype),
                                               int(nfft), int(hop)))

@@ -328,3 +328,34 @@ def test_calculate_psd_welch_call_shape(svc, oracle):
         svc.calculate_psd_welch(data[:, :100], fs, nfft)
     with pytest.raises(ValueError):
         svc.calculate_psd_welch(data, fs, 1000)
+
+
+# ---- renderSpectrogram + getColorForMagnitude (MC:1261-1291, MC:926-957) ------
+@pytest.mark.parametrize("colormap", [sa.CMAP_GRAYSCALE, sa.CMAP_HEATMAP])
+def test_render_is_bit_exact_on_the_same_tile(svc, oracle, colormap):
+    rng = np.random.default_rng(colormap)
+    W, N, H, fs = 173, 2048, 611, 1e6
+    tile = rng.uniform(-170, 60, size=(W, N)).astype(np.float32)
+    tile[5] = -150.0                                     # an EOF line
+    ref = oracle.render_spectrogram(tile.astype(np.float64), H, fs, -110.0, -15.0, colormap)
+    got = svc.render_spectrogram(tile, H, fs, -110.0, -15.0, colormap)
+    assert got.shape == (H, W, 4) and np.array_equal(got, ref)
+    import torch
+    got_d = svc.render_spectrogram(torch.from_numpy(tile).cuda(), H, fs, -110.0, -15.0, colormap)
+    torch.cuda.synchronize()
+    assert np.array_equal(got_d.cpu().numpy(), ref)
+
+
+def test_waterfall_render_end_to_end(svc, oracle):
+    # one redraw of MainController.updateDisplay(): canvasW lines at hop = nfft, then the image
+    dt, nfft, W, H, fs = "ci16_le", 1024, 200, 257, 2e6
+    iq = oracle.synth_iq(dt, 4, 0, (W - 3) * nfft)       # the last 3 columns run past the end -> -150 dB
+    wf = oracle.waterfall(iq, 0, dt, nfft, nfft, W)
+    for cmap in (sa.CMAP_GRAYSCALE, sa.CMAP_HEATMAP):
+        ref = oracle.render_spectrogram(wf, H, fs, -100.0, 0.0, cmap).astype(np.int16)
+        got = svc.waterfall_render(iq, 0, nfft, dt, W, H, fs, colormap=cmap).astype(np.int16)
+        d = np.abs(got - ref)
+        assert d.max() <= 1, "more than one 8-bit step"   # fp32 dB vs fp64 dB can flip a rounding
+        assert (d > 0).mean() < 2e-3
+    with pytest.raises(ValueError):
+        svc.render_spectrogram(np.zeros((4, 64), np.float32), 10, 1e6, colormap=7)

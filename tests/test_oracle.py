@@ -169,3 +169,32 @@ def test_synth_is_counter_based(oracle):
     a = oracle.synth_iq("ci16_le", 77, 0, 4096)
     b = oracle.synth_iq("ci16_le", 77, 1000, 1000)
     assert np.array_equal(a[4000:8000], b)      # any shard regenerates its own span
+
+
+def test_render_known_colours(oracle):
+    # MC:926-957 at hand-computable points: width 1, nfft 4, height 4 -> bins 0,1,2,3 bottom to top
+    fs, nfft = 4.0, 4
+    conv = oracle.display_conversion(fs, nfft)          # 10log10(1) + 20log10(4)
+    db = np.array([[-100.0, -50.0, 0.0, 50.0]]) + conv  # normalised 0, 0.5, 1, clamp(1.5)
+    g = oracle.render_spectrogram(db, 4, fs, -100.0, 0.0, 0)
+    assert g.shape == (4, 1, 4)
+    assert g[3, 0].tolist() == [0, 0, 0, 255]           # bottom row = bin 0 = black
+    assert g[2, 0].tolist() == [128, 128, 128, 255]     # 0.5 * 255 = 127.5 -> Math.round -> 128
+    assert g[1, 0].tolist() == [255, 255, 255, 255] and g[0, 0].tolist() == [255, 255, 255, 255]
+    h = oracle.render_spectrogram(db, 4, fs, -100.0, 0.0, 1)
+    assert h[3, 0].tolist() == [0, 0, 0, 255]           # n < 0.2 -> BLACK
+    assert h[2, 0].tolist() == [0, 0, 255, 255]         # n = 0.5 -> RED.interpolate(YELLOW, 0) = RED  (B,G,R,A)
+    assert h[1, 0].tolist() == [0, 255, 255, 255]       # n = 1 -> YELLOW
+    mid = oracle.render_spectrogram(np.array([[-65.0 + conv] * 4]), 4, fs, -100.0, 0.0, 1)   # n = 0.35: BLUE->RED halfway
+    assert mid[0, 0].tolist() == [128, 0, 128, 255]
+
+
+def test_render_decimation_matches_numpy(oracle):
+    rng = np.random.default_rng(3)
+    W, N, H, fs = 37, 1024, 301, 2.5e6
+    wf = rng.uniform(-160, 40, size=(W, N))
+    img = oracle.render_spectrogram(wf, H, fs, -120.0, -20.0, 0)
+    bins = (np.arange(H, dtype=np.float64) / H * N).astype(np.int64)            # MC:1280
+    n = np.clip((wf[:, bins] - oracle.display_conversion(fs, N) + 120.0) / 100.0, 0, 1)
+    ref = np.floor(n.astype(np.float32).astype(np.float64) * 255.0 + 0.5).astype(np.uint8)   # [W, H]
+    assert np.array_equal(img[::-1, :, 0].T, ref) and np.all(img[..., 3] == 255)
