@@ -39,7 +39,8 @@ def _newest_dep() -> float:
 
 def _compile(src: str) -> str:
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
-    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    extra = os.environ.get("SPEC_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))

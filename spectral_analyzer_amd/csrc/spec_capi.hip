@@ -33,7 +33,7 @@ struct spec_ctx {
     void *scratch = nullptr;   size_t scratch_bytes = 0;   // large-N transposes, Welch slabs
     void *scratch2 = nullptr;  size_t scratch2_bytes = 0;  // fallback Welch: power lines + accumulator
     // tuning / testing knobs (spec_set_option)
-    int64_t opt_force_generic = 0, opt_lines_per_wg = 0;
+    int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024;
     int n_cu = 256;
 };
 
@@ -186,6 +186,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     if (!key) return fail(c, SPEC_EINVAL, "spec_set_option: null key");
     if (!strcmp(key, "force_generic")) c->opt_force_generic = value;
     else if (!strcmp(key, "lines_per_wg")) c->opt_lines_per_wg = value < 0 ? 0 : value;
+    else if (!strcmp(key, "large_chunk_mb")) c->opt_large_chunk_mb = value < 1 ? 1 : value;
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
     return SPEC_OK;
 }
@@ -293,7 +294,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     a.kind = kind_of(dt, c->flags);
     a.be = is_be(dt);
     a.out_fmt = (int)fmt;
-    spec_status st = get_twiddles(c, log2n, f64, &a.tw);
+    // the four-step path takes its inter-step twiddles from the fp64 W_N table whatever the precision
+    spec_status st = get_twiddles(c, log2n, large ? true : f64, &a.tw);
     if (st != SPEC_OK) return st;
     st = get_window(c, log2n, f64, window, &a.win, nullptr, nullptr);
     if (st != SPEC_OK) return st;
@@ -304,7 +306,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         if ((st = get_twiddles(c, l1, f64, &tw1)) != SPEC_OK) return st;
         if ((st = get_twiddles(c, l2, f64, &tw2)) != SPEC_OK) return st;
         const size_t per_line = large_scratch_bytes_per_line(log2n, f64);
-        uint64_t chunk = (192ull << 20) / per_line;
+        uint64_t chunk = ((uint64_t)c->opt_large_chunk_mb << 20) / per_line;
         if (chunk == 0) chunk = 1;
         if (chunk > n_lines) chunk = n_lines;
         if ((st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)chunk * per_line)) != SPEC_OK) return st;

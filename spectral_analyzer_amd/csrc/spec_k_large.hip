@@ -25,7 +25,9 @@ template <typename R, int L1, int L2> struct Large {
     using PB = Plan<L2>;  // row FFTs
     static constexpr int CA = PA::LPW, CB = PB::LPW;          // lines (columns / rows) per workgroup
     static constexpr int SA = PA::N + 1, SB = PB::N + 1;      // padded LDS line strides (elements)
-    static constexpr size_t LDS_A = (size_t)CA * SA * sizeof(cx<R>), LDS_B = (size_t)CB * SB * sizeof(cx<R>);
+    // line buffers + the sub-FFT's own twiddle table W_N1 / W_N2 (global twiddle loads on the
+    // critical path of every pass were the main cost of the first version of these kernels)
+    static constexpr size_t LDS_A = ((size_t)CA * SA + PA::N) * sizeof(cx<R>), LDS_B = ((size_t)CB * SB + PB::N) * sizeof(cx<R>);
 };
 
 struct LargeArgs {
@@ -33,7 +35,8 @@ struct LargeArgs {
     uint32_t n_lines;
     uint32_t hop, bps;
     int kind, be;
-    const void *tw1, *tw2, *twn;  // W_N1, W_N2, W_N tables
+    const void *tw1, *tw2;        // W_N1, W_N2 tables (cx<R>)
+    const void *twn;              // W_N table, always fp64 (cx<double>): inter-step twiddles by recurrence
     const void *win;              // R[N] or nullptr
     void *scratch;                // cx<R>[n_lines][N], [n2][k1] order
     void *out;
@@ -54,6 +57,10 @@ __global__ __launch_bounds__(Plan<L1>::WG) void large_cols_kernel(const LargeArg
     const uint8_t *src = a.iq + (uint64_t)line * a.hop * a.bps;
     const R *__restrict__ win = static_cast<const R *>(a.win);
 
+    // sub-FFT twiddles W_N1 into LDS
+    cx<R> *tab = lds + (size_t)LG::CA * LG::SA;
+    for (int e = tid; e < PA::N; e += PA::WG) tab[e] = static_cast<const cx<R> *>(a.tw1)[e];
+
     cx<R> v[PA::E];
 #pragma unroll
     for (int m = 0; m < PA::E; ++m) {
@@ -61,14 +68,20 @@ __global__ __launch_bounds__(Plan<L1>::WG) void large_cols_kernel(const LargeArg
         v[m] = decode_sample<R>(src + (uint64_t)n * a.bps, a.kind, a.be != 0);
         if (win) { const R w = win[n]; v[m].x *= w; v[m].y *= w; }
     }
-    fft_line_remap<R, L1>(v, t0, lds + (size_t)q0 * LG::SA, t1, lds + (size_t)q1 * LG::SA,
-                          static_cast<const cx<R> *>(a.tw1));
-    const cx<R> *__restrict__ twn = static_cast<const cx<R> *>(a.twn);
-    cx<R> *dst = static_cast<cx<R> *>(a.scratch) + (uint64_t)line * LG::N + (uint64_t)(c0 + q1) * LG::N1;
+    __syncthreads();  // table visible
+    fft_line_remap<R, L1>(v, t0, lds + (size_t)q0 * LG::SA, t1, lds + (size_t)q1 * LG::SA, tab);
+    // inter-step twiddle W_N^(n2 k1), k1 = t1 + m T: W^(n2 t1) * (W^(n2 T))^m by recurrence in
+    // fp64 (two table reads per thread instead of sixteen scattered ones; 15 roundings of 1e-16)
+    const cx<double> *__restrict__ twn = static_cast<const cx<double> *>(a.twn);
+    const uint32_t n2 = c0 + q1;
+    cx<double> w = twn[n2 * (uint32_t)t1];
+    const cx<double> step = twn[n2 * (uint32_t)PA::T];
+    cx<R> *dst = static_cast<cx<R> *>(a.scratch) + (uint64_t)line * LG::N + (uint64_t)n2 * LG::N1;
 #pragma unroll
     for (int m = 0; m < PA::E; ++m) {
-        const int k1 = t1 + m * PA::T;
-        dst[k1] = cmul(v[m], twn[(c0 + q1) * k1]);  // W_N^(n2 k1)
+        const cx<double> z = cmul(cx<double>{(double)v[m].x, (double)v[m].y}, w);
+        dst[t1 + m * PA::T] = cx<R>{(R)z.x, (R)z.y};
+        w = cmul(w, step);
     }
 }
 
@@ -84,11 +97,14 @@ __global__ __launch_bounds__(Plan<L2>::WG) void large_rows_kernel(const LargeArg
     const uint32_t line = blockIdx.x / TILES, r0 = (blockIdx.x % TILES) * LG::CB;
     const cx<R> *src = static_cast<const cx<R> *>(a.scratch) + (uint64_t)line * LG::N + r0 + q0;
 
+    cx<R> *tab = lds + (size_t)LG::CB * LG::SB;
+    for (int e = tid; e < PB::N; e += PB::WG) tab[e] = static_cast<const cx<R> *>(a.tw2)[e];
     cx<R> v[PB::E];
 #pragma unroll
     for (int m = 0; m < PB::E; ++m) v[m] = src[(uint64_t)(t0 + m * PB::T) * LG::N1];  // [n2][k1]
+    __syncthreads();  // table visible
     // no role change is needed here (k1 stays the fast index), only the padded line stride
-    fft_line<R, L2>(v, t0, lds + (size_t)q0 * LG::SB, static_cast<const cx<R> *>(a.tw2));
+    fft_line<R, L2>(v, t0, lds + (size_t)q0 * LG::SB, tab);
     const uint64_t base = (uint64_t)line * LG::N;
 #pragma unroll
     for (int m = 0; m < PB::E; ++m) {

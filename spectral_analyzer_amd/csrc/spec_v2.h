@@ -304,7 +304,13 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
         const_cast<uint8_t *>(a.iq) + (uint64_t)unit * a.unit_stride + (uint64_t)line0 * line_bytes, 0,
         (lines_wg - 1) * line_bytes + (uint32_t)N * BPS, 0x00020000);
     const int voff = (int)(q * a.run * line_bytes) + t * BPS;  // this sub-line's run, this thread's column
-    constexpr int AUX = 2;                                      // non-temporal
+#ifndef SPEC_LD_AUX
+#define SPEC_LD_AUX 2  // non-temporal loads
+#endif
+#ifndef SPEC_ST_AUX
+#define SPEC_ST_AUX 2  // non-temporal stores
+#endif
+    constexpr int AUX = SPEC_LD_AUX, ST_AUX = SPEC_ST_AUX;
     // overlap shift: SH > 0 promises hop == SH * T, i.e. the line slides by SH registers
     constexpr int NEW = SH > 0 ? SH : E;
 
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 #pragma unroll
             for (int m = 0; m < E; ++m)  // (t + m T + N/2) mod N   (SS:78)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, ovoff,
-                                                      out_off + ((m + E / 2) & (E - 1)) * T * 4, AUX);
+                                                      out_off + ((m + E / 2) & (E - 1)) * T * 4, ST_AUX);
         }
     };
     for (uint32_t line = 0; line < iters; ++line) do_line(line);
