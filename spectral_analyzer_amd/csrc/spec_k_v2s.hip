@@ -6,7 +6,8 @@ namespace specgpu {
 bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, uint32_t hop) {
     // 64 and 128 points stay on the generic kernel: with 16 points per thread a line would be
     // 4 or 8 lanes wide (32 / 64-byte global segments) and measured slower
-    if (log2n < 8 || log2n > 14 || be) return false;
+    if (log2n < 8 || log2n > 14) return false;
+    (void)be;  // either byte order
     if (kind != K_CF32 && kind != K_CI16 && kind != K_CU8 && kind != K_CI8) return false;
     if (out_fmt != OUT_DB20_F32 && out_fmt != OUT_POW_F32) return false;
     // 32-bit offsets inside a workgroup's span
@@ -28,7 +29,7 @@ hipError_t launch_v2_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream
     a.iq = w.iq; a.unit_stride = 0; a.n_units = 1; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.run = run;
     const uint32_t per_wg = (uint32_t)v2_lpw(log2n) * run;
     a.wgs_per_unit = (a.n_lines + per_wg - 1) / per_wg;
-    a.tw = w.tw; a.win = w.win; a.out = w.out; a.out_fmt = w.out_fmt;
+    a.tw = w.tw; a.win = w.win; a.out = w.out; a.out_fmt = w.out_fmt; a.be = w.be;
     return v2_launch_n<0>(a, log2n, w.kind, s);
 }
 

@@ -75,6 +75,7 @@ template <> struct Raw2<K_CF32> {
         return __builtin_amdgcn_raw_buffer_load_b64(r, v, s, AUX);
     }
     static __device__ __forceinline__ v2f dec(type u) { return v2f{__uint_as_float(u.x), __uint_as_float(u.y)}; }
+    static __device__ __forceinline__ type swap(type u) { return type{__builtin_bswap32(u.x), __builtin_bswap32(u.y)}; }
 };
 template <> struct Raw2<K_CI16> {
     using type = uint32_t;
@@ -86,6 +87,8 @@ template <> struct Raw2<K_CI16> {
     static __device__ __forceinline__ v2f dec(type u) {
         return v2f{(float)(int16_t)(u & 0xFFFFu), (float)((int32_t)u >> 16)};
     }
+    // big-endian file: swap the two bytes of each 16-bit component
+    static __device__ __forceinline__ type swap(type u) { return ((u & 0x00FF00FFu) << 8) | ((u >> 8) & 0x00FF00FFu); }
 };
 template <> struct Raw2<K_CI8> {
     using type = uint16_t;
@@ -95,6 +98,7 @@ template <> struct Raw2<K_CI8> {
         return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, v, s, AUX);
     }
     static __device__ __forceinline__ v2f dec(type u) { return v2f{(float)(int8_t)(u & 0xFF), (float)(int8_t)(u >> 8)}; }
+    static __device__ __forceinline__ type swap(type u) { return u; }
 };
 template <> struct Raw2<K_CU8> {
     using type = uint16_t;
@@ -106,6 +110,7 @@ template <> struct Raw2<K_CU8> {
     static __device__ __forceinline__ v2f dec(type u) {
         return v2f{(float)(u & 0xFF), (float)(u >> 8)} - v2f{127.5f, 127.5f};
     }
+    static __device__ __forceinline__ type swap(type u) { return u; }
 };
 
 // LDS layout of an exchange written with a stride narrower than 16 elements: one
@@ -263,6 +268,7 @@ struct V2Args {
     const void *tw, *win;
     void *out;              // spectrogram: float[n_lines][N]; Welch: float slabs [unit][wg*LPW + q][N]
     int out_fmt;
+    int be;                 // big-endian components
 };
 
 // MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums
@@ -353,10 +359,16 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 #pragma unroll
             for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
         }
+        if (a.be) {  // big-endian recording (SMH:87-91): wave-uniform branch, one swap per sample
 #pragma unroll
-        for (int m = 0; m < E; ++m) {
-            v[m] = RW::dec(raw[m]);
-            if constexpr (HAS_WIN) v[m] *= v2f{w[m], w[m]};
+            for (int m = 0; m < E; ++m) v[m] = RW::dec(RW::swap(raw[m]));
+        } else {
+#pragma unroll
+            for (int m = 0; m < E; ++m) v[m] = RW::dec(raw[m]);
+        }
+        if constexpr (HAS_WIN) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};
         }
         if constexpr (KEEP) {
             if constexpr (SH > 0 && SH < E) {
