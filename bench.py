@@ -41,6 +41,18 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 SEED = 0x5EC7A11A
 
 
+def usable_cores() -> int:
+    """CPU threads this process may actually run on: affinity mask, capped by a cgroup quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,7 +61,7 @@ def main() -> None:
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--log2-samples", type=int, default=None, help="override samples per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2-samples", type=int, default=26, help="CPU baseline sample: first 2^k samples")
+    ap.add_argument("--cpu-log2-samples", type=int, default=28, help="CPU baseline sample: first 2^k samples")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,7 +151,7 @@ def main() -> None:
             cs = min(1 << args.cpu_log2_samples, n_samples)
             host = iq[:cs * bps].cpu().numpy()
             cl = (cs - nfft) // hop + 1
-            cores = len(os.sched_getaffinity(0))
+            cores = usable_cores()
             secs, _ = so.time_waterfall(host, datatype, nfft, hop, cl, window, cores)
             cpu_baseline = {"value": cl / secs, "unit": "lines/s", "cores": cores, "kind": "port",
                             "sample": "first 2^%d samples of the same recording (%d lines), fp64 C oracle "
