@@ -1,0 +1,67 @@
+"""Seeded randomised differential test of the whole dispatch (packed family, generic kernels,
+four-step, EOF fill, staging) against the oracle: random datatype / nfft / hop / start / lines /
+window / output format.  Sizes stay small so the CPU oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+import spectral_analyzer_amd as sa
+from test_gpu_parity import check_fp32, check_fp64
+
+pytestmark = pytest.mark.gpu
+DTYPES = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "cf64_be"]
+
+
+def _cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        log2n = int(rng.choice([1, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]))
+        nfft = 1 << log2n
+        hop = int(rng.choice([nfft, nfft // 2 or 1, nfft // 4 or 1, int(rng.integers(1, 3 * nfft + 1)), 9 * nfft]))
+        dt = str(rng.choice(DTYPES))
+        budget = 1 << 17                                  # samples the oracle has to transform
+        n_lines = int(rng.integers(1, max(2, min(300, budget // nfft))))
+        if hop > 4 * nfft:
+            n_lines = min(n_lines, 8)
+        extra = int(rng.integers(0, 3))                   # lines past the end -> EOF fill
+        start = int(rng.integers(0, 50))
+        window = int(rng.integers(0, 2))
+        fmt = int(rng.choice([sa.OUT_DB20_F32, sa.OUT_DB20_F32, sa.OUT_POW_F32, sa.OUT_DB20_F64]))
+        on_device = bool(rng.integers(0, 2))
+        lpw = int(rng.choice([0, 0, 1, 3, 50]))
+        yield dt, nfft, hop, n_lines, extra, start, window, fmt, on_device, lpw, int(rng.integers(1, 1 << 30))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_requests_match_oracle(svc, oracle, seed):
+    import torch
+    for dt, nfft, hop, n_lines, extra, start, window, fmt, on_device, lpw, s in _cases(seed, 60):
+        bps = oracle.bytes_per_sample(dt)
+        start_byte = start * bps
+        n_samples = start + (n_lines - 1) * hop + nfft
+        iq = oracle.synth_iq(dt, s, 0, n_samples)
+        total = n_lines + extra
+        tag = (dt, nfft, hop, n_lines, extra, start, window, fmt, on_device, lpw)
+        svc.set_option("lines_per_wg", lpw)
+        try:
+            buf = torch.from_numpy(iq).cuda() if on_device else iq
+            got = svc.compute_waterfall(buf, start_byte, nfft, dt, total, hop=hop, window=window, out_fmt=fmt)
+            if on_device:
+                torch.cuda.synchronize()
+                got = got.cpu().numpy()
+        finally:
+            svc.set_option("lines_per_wg", 0)
+        assert got.shape == (total, nfft), tag
+        assert np.all(got[n_lines:] == -150.0), tag       # MC:994-998
+        if fmt == sa.OUT_POW_F32:
+            ref = oracle.waterfall(iq, start_byte, dt, nfft, hop, n_lines, window, power=True)
+            tol = 4e-6 * max(np.log2(nfft), 2)
+            assert np.abs(got[:n_lines] - ref).max() <= tol * ref.max(), tag
+        else:
+            ref = oracle.waterfall(iq, start_byte, dt, nfft, hop, n_lines, window)
+            try:
+                if fmt == sa.OUT_DB20_F64:
+                    check_fp64(got[:n_lines], ref)
+                else:
+                    check_fp32(got[:n_lines], ref, max(nfft, 4))
+            except AssertionError as e:
+                raise AssertionError("%s: %s" % (tag, e))
