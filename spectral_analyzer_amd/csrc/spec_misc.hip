@@ -19,25 +19,42 @@ hipError_t launch_fill(void *out, uint64_t n, double value, int is_f64, hipStrea
     return hipGetLastError();
 }
 
-// Sum the partial slabs of each PSD in a fixed order (bitwise reproducible),
-// scale, fftshift, optional 10 log10(P + 1e-20).
-__global__ void welch_finalize_kernel(const float *__restrict__ partial, uint32_t n_slabs, uint32_t nfft,
-                                      double norm, int db, float *__restrict__ psd_out) {
-    const uint32_t psd = blockIdx.y;
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nfft) return;
-    const float *p = partial + (uint64_t)psd * n_slabs * nfft + k;
+// Sum the partial slabs of each PSD, scale, fftshift, optional 10 log10(P + 1e-20).  A block
+// owns 32 bins; its 8 lanes per bin each sum every 8th slab and are combined in lane order, so
+// the result does not depend on scheduling (bitwise reproducible, no atomics) while a single
+// 256-slab PSD is no longer one long dependent chain per bin.
+__global__ __launch_bounds__(256) void welch_finalize_kernel(const float *__restrict__ partial, uint32_t n_slabs,
+                                                             uint32_t nfft, double norm, int db,
+                                                             float *__restrict__ psd_out) {
+    __shared__ double part[8][32];
+    const uint32_t psd = blockIdx.y, b = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    const uint32_t k = blockIdx.x * 32 + b;
     double acc = 0;
-    for (uint32_t sl = 0; sl < n_slabs; ++sl) acc += (double)p[(uint64_t)sl * nfft];
-    const double v = acc * norm;
-    const uint32_t ks = (k + nfft / 2) & (nfft - 1);
-    psd_out[(uint64_t)psd * nfft + ks] = db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+    if (k < nfft) {
+        const float *p = partial + (uint64_t)psd * n_slabs * nfft + k;
+#pragma unroll 4
+        for (uint32_t sl = lane; sl < n_slabs; sl += 8) acc += (double)p[(uint64_t)sl * nfft];
+    }
+    part[lane][b] = acc;
+    __syncthreads();
+    if (lane == 0 && k < nfft) {
+        double t = part[0][b];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) t += part[l][b];
+        const double v = t * norm;
+        const uint32_t ks = (k + nfft / 2) & (nfft - 1);
+        psd_out[(uint64_t)psd * nfft + ks] = db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+    }
 }
 
 hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs, uint32_t nfft,
                                  double norm, int db, float *psd_out, hipStream_t s) {
-    hipLaunchKernelGGL(welch_finalize_kernel, dim3((nfft + 255) / 256, n_psd), dim3(256), 0, s, partial, n_slabs,
-                       nfft, norm, db, psd_out);
+    for (uint32_t p0 = 0; p0 < n_psd; p0 += 65535) {  // grid.y limit
+        const uint32_t np = n_psd - p0 < 65535 ? n_psd - p0 : 65535;
+        hipLaunchKernelGGL(welch_finalize_kernel, dim3((nfft + 31) / 32, np), dim3(256), 0, s,
+                           partial + (uint64_t)p0 * n_slabs * nfft, n_slabs, nfft, norm, db,
+                           psd_out + (uint64_t)p0 * nfft);
+    }
     return hipGetLastError();
 }
 

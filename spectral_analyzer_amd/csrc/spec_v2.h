@@ -272,7 +272,7 @@ struct V2Args {
 };
 
 // MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums
-template <int L, int KIND, int SH, bool HAS_WIN, int MODE, int OCC>
+template <int L, int KIND, int SH, bool HAS_WIN, int MODE, bool BE, int OCC>
 __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     using PL = Plan2<L>;
     using RW = Raw2<KIND>;
@@ -359,13 +359,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 #pragma unroll
             for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
         }
-        if (a.be) {  // big-endian recording (SMH:87-91): wave-uniform branch, one swap per sample
 #pragma unroll
-            for (int m = 0; m < E; ++m) v[m] = RW::dec(RW::swap(raw[m]));
-        } else {
-#pragma unroll
-            for (int m = 0; m < E; ++m) v[m] = RW::dec(raw[m]);
-        }
+        for (int m = 0; m < E; ++m) v[m] = RW::dec(BE ? RW::swap(raw[m]) : raw[m]);  // SMH:87-91 byte order
         if constexpr (HAS_WIN) {
 #pragma unroll
             for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};
@@ -408,15 +403,16 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     }
 }
 
-template <int L, int KIND, int SH, bool HAS_WIN, int MODE> hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
+template <int L, int KIND, int SH, bool HAS_WIN, int MODE, bool BE = false>
+hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
     using PL = Plan2<L>;
     constexpr size_t lds = p2_lds_bytes<L>();
     // Minimum waves per SIMD asked of the register allocator, chosen so that the kernel does
     // not spill: about 104 VGPRs of FFT state + 32 (cf32) or 16 raw sample registers + 16 for a
     // window + 16 for Welch sums.  1024-thread groups need 4 (128 VGPRs) to exist at all.
     constexpr int NEED = 104 + (KIND == K_CF32 ? 32 : 16) + (HAS_WIN ? 16 : 0) + (MODE == 1 ? 16 : 0);
-    constexpr int WAVES_PER_SIMD = PL::WG == 1024 ? 4 : PL::WG == 512 ? 2 : NEED <= 128 ? 4 : NEED <= 168 ? 3 : 2;
-    auto kern = v2_kernel<L, KIND, SH, HAS_WIN, MODE, WAVES_PER_SIMD>;
+    constexpr int WAVES_PER_SIMD = PL::WG == 1024 ? 4 : PL::WG == 512 ? 2 : NEED <= 120 ? 4 : NEED <= 152 ? 3 : 2;
+    auto kern = v2_kernel<L, KIND, SH, HAS_WIN, MODE, BE, WAVES_PER_SIMD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -427,11 +423,17 @@ template <int L, int KIND, int SH, bool HAS_WIN, int MODE> hipError_t v2_launch1
 }
 
 // Instantiation matrix: cf32 / ci16 carry the register-reuse variants (hop = 8 T and 4 T,
-// i.e. 50 % and 75 % overlap); the byte formats and every other hop take SH = 0.
+// i.e. 50 % and 75 % overlap); the byte formats, big-endian files and every other hop take SH = 0.
 // Welch always multiplies by a window table (all ones for the rectangular window).
 template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hipStream_t s) {
     constexpr int T = Plan2<L>::T;
     constexpr bool FAST = KIND == K_CF32 || KIND == K_CI16;
+    if constexpr (FAST) {  // big-endian files: one variant per mode (no register reuse), byte swap at decode
+        if (a.be) {
+            if constexpr (MODE == 1) return v2_launch1<L, KIND, 0, true, 1, true>(a, s);
+            else return a.win ? v2_launch1<L, KIND, 0, true, 0, true>(a, s) : v2_launch1<L, KIND, 0, false, 0, true>(a, s);
+        }
+    }
     if constexpr (MODE == 1) {
         if constexpr (FAST) {
             if (a.hop == 8 * T) return v2_launch1<L, KIND, 8, true, 1>(a, s);
