@@ -1,0 +1,68 @@
+// specgpu.hpp -- header-only C++ mirror of the reference service on top of the C ABI
+// (include/specgpu.h).  Same method name and argument meaning as
+//   double[] SpectralService.computeMagnitudes(MappedByteBuffer, int startByte, int nfft, String datatype)
+// (services/SpectralService.java:33); errors become the exceptions the Java code path raises:
+// SPEC_EINVAL -> std::invalid_argument (IllegalArgumentException), SPEC_ERANGE -> std::out_of_range
+// (IndexOutOfBoundsException), everything else -> std::runtime_error.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "specgpu.h"
+
+namespace specgpu {
+
+class SpectralService {
+public:
+    explicit SpectralService(int device = 0, void *hip_stream = nullptr, uint32_t flags = 0) {
+        check(spec_create(device, hip_stream, flags, &ctx_), nullptr);
+    }
+    ~SpectralService() { spec_destroy(ctx_); }
+    SpectralService(const SpectralService &) = delete;
+    SpectralService &operator=(const SpectralService &) = delete;
+
+    // SpectralService.java:33-85; `big_endian` is the buffer's byte order (SigMfHelper.java:87-91)
+    std::vector<double> computeMagnitudes(const void *buffer, uint64_t capacity, int64_t startByte, uint32_t nfft,
+                                          const std::string &datatype, bool big_endian) const {
+        std::vector<double> out(nfft);
+        check(spec_compute_magnitudes(ctx_, buffer, capacity, startByte, nfft, datatype.c_str(), big_endian, out.data()), ctx_);
+        return out;
+    }
+
+    // the slice loop of MainController.updateDisplay (MainController.java:980-999), host buffers
+    std::vector<float> computeWaterfall(const void *buffer, uint64_t capacity, uint64_t startByte, uint32_t nfft,
+                                        uint32_t hop, uint64_t nLines, const std::string &datatype,
+                                        spec_window window = SPEC_WIN_RECT) const {
+        std::vector<float> out(nLines * nfft);
+        check(spec_waterfall(ctx_, buffer, 0, capacity, startByte, spec_dtype_from_sigmf(datatype.c_str()), nfft, hop,
+                             nLines, window, SPEC_OUT_DB20_F32, -150.0, out.data(), 0), ctx_);
+        return out;
+    }
+
+    // PowerSpectralDensity.calculatePsdWelch(data, fs, nfft) (AnalysisDialogController.java:308-312):
+    // returns {freq, psd}
+    std::vector<std::vector<double>> calculatePsdWelch(const double *re, const double *im, uint64_t n, double fs,
+                                                       uint32_t nfft) const {
+        std::vector<double> f(nfft);
+        std::vector<float> p(nfft);
+        check(spec_welch_psd_planar_f64(ctx_, re, im, n, nfft, nfft / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY, fs, 0,
+                                        f.data(), p.data()), ctx_);
+        return {f, std::vector<double>(p.begin(), p.end())};
+    }
+
+    spec_ctx *handle() const { return ctx_; }
+
+private:
+    static void check(spec_status st, const spec_ctx *ctx) {
+        if (st == SPEC_OK) return;
+        const std::string msg = std::string(spec_status_string(st)) + ": " + spec_last_error(ctx);
+        if (st == SPEC_EINVAL) throw std::invalid_argument(msg);
+        if (st == SPEC_ERANGE) throw std::out_of_range(msg);
+        throw std::runtime_error(msg);
+    }
+    spec_ctx *ctx_ = nullptr;
+};
+
+}  // namespace specgpu

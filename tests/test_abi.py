@@ -84,3 +84,23 @@ def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_header_is_plain_c_and_cpp(tmp_path):
+    """include/specgpu.h compiles as C99 and as C++17 with nothing but the standard headers; the C++
+    mirror include/specgpu.hpp and the example host build against the library without HIP or torch."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    c = tmp_path / "t.c"
+    c.write_text('#include "specgpu.h"\nint main(void) { return (int)spec_bytes_per_sample(SPEC_DT_CI16_LE) - 4; }\n')
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + inc, str(c), "-L" + libdir,
+                           "-lspecgpu", "-Wl,-rpath," + libdir, "-o", str(tmp_path / "t_c")])
+    assert subprocess.call([str(tmp_path / "t_c")]) == 0
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + inc,
+                           os.path.join(ROOT, "integration", "cpp", "example.cpp"), "-L" + libdir, "-lspecgpu",
+                           "-Wl,-rpath," + libdir, "-o", str(tmp_path / "example")])
+    # without a GPU the example reports the create failure and exits 2; with one it exits 0
+    rc = subprocess.call([str(tmp_path / "example")])
+    import torch
+    assert rc == (0 if torch.cuda.is_available() else 2)

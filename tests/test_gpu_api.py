@@ -359,3 +359,17 @@ def test_waterfall_render_end_to_end(svc, oracle):
         assert (d > 0).mean() < 2e-3
     with pytest.raises(ValueError):
         svc.render_spectrogram(np.zeros((4, 64), np.float32), 10, 1e6, colormap=7)
+
+
+def test_cpp_host_example(tmp_path):
+    """The C++ mirror (include/specgpu.hpp) driven by a plain g++ program."""
+    import subprocess
+    from spectral_analyzer_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "example")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "integration", "cpp", "example.cpp"), "-L" + libdir, "-lspecgpu",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "example ok" in out.stdout, out.stdout + out.stderr
