@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""In-process A/B of kernel variants (interleaved rounds, median/min) on the
-cfg2 / cfg3 workloads.  Development tool, not part of the product.
+"""In-process A/B of run lengths (and generic vs packed kernels) on the cfg2 / cfg3 workloads:
+interleaved rounds at a settled clock, median/min.  Development tool, not part of the product.
 
-    python tools/tune.py --workload cfg2 --variants 0,2,4,6 --lpw 0,64 --rounds 5
+    python tools/tune.py --workload cfg2 --lpw 0,16,64 --rounds 5 [--generic] [--window 1] [--hop 1024]
 """
 import argparse, os, sys
 import numpy as np, torch
@@ -12,7 +12,6 @@ from spectral_analyzer_amd import _lib as L
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="cfg2")
-ap.add_argument("--variants", default="0")
 ap.add_argument("--lpw", default="0")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--log2", type=int, default=30)
@@ -34,9 +33,8 @@ svc.set_option("force_generic", 1)
 svc.compute_waterfall(iq, 0, nfft, dt, n_lines, hop=hop, window=args.window, out=ref)
 torch.cuda.synchronize()
 cfgs = [("generic", None, 0)] if args.generic else []
-for v in [int(x) for x in args.variants.split(",")]:
-    for l in [int(x) for x in args.lpw.split(",")]:
-        cfgs.append(("v%d/lpw%d" % (v, l), v, l))
+for l in [int(x) for x in args.lpw.split(",")]:
+    cfgs.append(("packed/lpw%d" % l, 0, l))
 times = {c[0]: [] for c in cfgs}
 b_line = hop * bps + nfft * 4
 # warm the clocks: the chip needs ~10 back-to-back launches to reach its steady state
