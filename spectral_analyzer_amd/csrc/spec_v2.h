@@ -422,28 +422,27 @@ hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Instantiation matrix: cf32 / ci16 carry the register-reuse variants (hop = 8 T and 4 T,
-// i.e. 50 % and 75 % overlap); the byte formats, big-endian files and every other hop take SH = 0.
+// Instantiation matrix: register-reuse variants for hop = 8 T (50 % overlap) in every format, for
+// hop = 4 T (75 %) in cf32 / ci16 and in every Welch kernel; big-endian files and every other hop
+// take SH = 0 (the overlap then comes from L2).
 // Welch always multiplies by a window table (all ones for the rectangular window).
 template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hipStream_t s) {
     constexpr int T = Plan2<L>::T;
-    constexpr bool FAST = KIND == K_CF32 || KIND == K_CI16;
-    if constexpr (FAST) {  // big-endian files: one variant per mode (no register reuse), byte swap at decode
+    constexpr bool WIDE = KIND == K_CF32 || KIND == K_CI16;  // formats with a byte order
+    if constexpr (WIDE) {  // big-endian files: one variant per mode (no register reuse), byte swap at decode
         if (a.be) {
             if constexpr (MODE == 1) return v2_launch1<L, KIND, 0, true, 1, true>(a, s);
             else return a.win ? v2_launch1<L, KIND, 0, true, 0, true>(a, s) : v2_launch1<L, KIND, 0, false, 0, true>(a, s);
         }
     }
     if constexpr (MODE == 1) {
-        if constexpr (FAST) {
-            if (a.hop == 8 * T) return v2_launch1<L, KIND, 8, true, 1>(a, s);
-            if (a.hop == 4 * T) return v2_launch1<L, KIND, 4, true, 1>(a, s);
-        }
+        if (a.hop == 8 * T) return v2_launch1<L, KIND, 8, true, 1>(a, s);
+        if (a.hop == 4 * T) return v2_launch1<L, KIND, 4, true, 1>(a, s);
         return v2_launch1<L, KIND, 0, true, 1>(a, s);
     } else {
         const bool win = a.win != nullptr;
-        if constexpr (FAST) {
-            if (a.hop == 8 * T) return win ? v2_launch1<L, KIND, 8, true, 0>(a, s) : v2_launch1<L, KIND, 8, false, 0>(a, s);
+        if (a.hop == 8 * T) return win ? v2_launch1<L, KIND, 8, true, 0>(a, s) : v2_launch1<L, KIND, 8, false, 0>(a, s);
+        if constexpr (WIDE) {
             if (a.hop == 4 * T) return win ? v2_launch1<L, KIND, 4, true, 0>(a, s) : v2_launch1<L, KIND, 4, false, 0>(a, s);
         }
         return win ? v2_launch1<L, KIND, 0, true, 0>(a, s) : v2_launch1<L, KIND, 0, false, 0>(a, s);
