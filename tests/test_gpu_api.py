@@ -373,3 +373,28 @@ def test_cpp_host_example(tmp_path):
                            "-Wl,-rpath," + libdir, "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "example ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_two_contexts_two_streams(oracle):
+    """Distinct contexts are independent (one per host thread / stream): run two from two threads."""
+    import threading
+    import torch
+    results = {}
+
+    def work(name, datatype, nfft):
+        st = torch.cuda.Stream()
+        with sa.SpectralService(0, stream=st.cuda_stream) as s:
+            iq = oracle.synth_iq(datatype, 5, 0, 64 * nfft)
+            d = torch.from_numpy(iq).cuda()
+            outs = [s.compute_waterfall(d, 0, nfft, datatype, 127, hop=nfft // 2) for _ in range(20)]
+            s.synchronize()
+            results[name] = (outs[-1].cpu().numpy(), oracle.waterfall(iq, 0, datatype, nfft, nfft // 2, 127), nfft)
+
+    th = [threading.Thread(target=work, args=("a", "cf32_le", 4096)),
+          threading.Thread(target=work, args=("b", "ci16_le", 1024))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for got, ref, nfft in results.values():
+        check_fp32(got, ref, nfft)
