@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 namespace specgpu {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -119,11 +121,59 @@ __device__ __forceinline__ void pk_dft16(v2f (&u)[16]) {
     for (int k = 0; k < 16; ++k) u[k] = y[k];
 }
 
+// W_32^r = exp(-2 pi i r / 32), r = 0 .. 15
+__device__ static constexpr float kW32[16][2] = {
+    {1.00000000000000000000f, -0.00000000000000000000f}, {0.98078528040323043058f, -0.19509032201612824808f},
+    {0.92387953251128673848f, -0.38268343236508978178f}, {0.83146961230254523567f, -0.55557023301960217765f},
+    {0.70710678118654757274f, -0.70710678118654746172f}, {0.55557023301960228867f, -0.83146961230254523567f},
+    {0.38268343236508983729f, -0.92387953251128673848f}, {0.19509032201612833135f, -0.98078528040323043058f},
+    {0.00000000000000000000f, -1.00000000000000000000f}, {-0.19509032201612819257f, -0.98078528040323043058f},
+    {-0.38268343236508972627f, -0.92387953251128673848f}, {-0.55557023301960195560f, -0.83146961230254545772f},
+    {-0.70710678118654746172f, -0.70710678118654757274f}, {-0.83146961230254534669f, -0.55557023301960217765f},
+    {-0.92387953251128673848f, -0.38268343236508989280f}, {-0.98078528040323043058f, -0.19509032201612860891f}};
+
+// a * (-i)
+__device__ __forceinline__ v2f pk_mul_mi(v2f a) { return pk_swap(a) * v2f{1.0f, -1.0f}; }
+
+// a * W_32^R for a compile-time R
+template <int R> __device__ __forceinline__ v2f pk_mul_w32(v2f a) {
+    if constexpr (R == 0) return a;
+    else if constexpr (R == 8) return pk_mul_mi(a);
+    else return pk_cmul_const(a, kW32[R][0], kW32[R][1]);
+}
+
+// 32-point forward DFT in place, natural order out: even / odd halves (two 16-point DFTs), then
+// X[k] = A0[k] + W_32^k A1[k],  X[k + 16] = A0[k] - W_32^k A1[k]
+template <int K> __device__ __forceinline__ void pk_dft32_comb(v2f (&u)[32], const v2f (&a0)[16], const v2f (&a1)[16]) {
+    if constexpr (K == 8) {  // W_32^8 = -i: folded into the additions
+        u[K] = pk_add_mi(a0[K], a1[K]);
+        u[K + 16] = pk_sub_mi(a0[K], a1[K]);
+    } else {
+        const v2f w = pk_mul_w32<K>(a1[K]);
+        u[K] = a0[K] + w;
+        u[K + 16] = a0[K] - w;
+    }
+}
+template <int... K>
+__device__ __forceinline__ void pk_dft32_comb_all(v2f (&u)[32], const v2f (&a0)[16], const v2f (&a1)[16],
+                                                  std::integer_sequence<int, K...>) {
+    (pk_dft32_comb<K>(u, a0, a1), ...);
+}
+__device__ __forceinline__ void pk_dft32(v2f (&u)[32]) {
+    v2f a0[16], a1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a0[j] = u[2 * j]; a1[j] = u[2 * j + 1]; }
+    pk_dft16(a0);
+    pk_dft16(a1);
+    pk_dft32_comb_all(u, a0, a1, std::make_integer_sequence<int, 16>{});
+}
+
 template <int RADIX> __device__ __forceinline__ void pk_dft(v2f (&u)[RADIX]) {
     if constexpr (RADIX == 2) pk_dft2(u[0], u[1]);
     else if constexpr (RADIX == 4) pk_dft4(u[0], u[1], u[2], u[3]);
     else if constexpr (RADIX == 8) pk_dft8(u);
-    else pk_dft16(u);
+    else if constexpr (RADIX == 16) pk_dft16(u);
+    else pk_dft32(u);
 }
 
 }  // namespace specgpu

@@ -16,7 +16,7 @@ bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, u
 
 int v2_lpw(int log2n) {
     switch (log2n) {
-    case 6: return Plan2<6>::LPW;   case 7: return Plan2<7>::LPW;   case 8: return Plan2<8>::LPW;
+    case 8: return Plan2<8>::LPW;
     case 9: return Plan2<9>::LPW;   case 10: return Plan2<10>::LPW; case 11: return Plan2<11>::LPW;
     case 12: return Plan2<12>::LPW; case 13: return Plan2<13>::LPW; case 14: return Plan2<14>::LPW;
     default: return 1;

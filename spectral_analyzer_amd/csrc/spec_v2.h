@@ -1,12 +1,14 @@
 // spec_v2.h -- the packed-fp32 kernel family for every LDS-resident size
 // (nfft = 64 ... 16384) and the little-endian / byte datatypes (cf32, ci16, cu8,
 // ci8): spectrogram lines and Welch partial sums:
-//   * plans put the SMALL radix first (64 = 4x16 ... 16384 = 4x16x16x16) so that
-//     every pass but the last has few distinct twiddles (LDS tables, stored as
-//     (c, d, -d, d)) and the last pass is always one radix-16 butterfly per
-//     thread with its 15 twiddles W_N^(r t) in registers;
-//   * a line is owned by T = nfft/16 threads.  Up to 1024 points that is at most
-//     one wave, so the LDS exchanges are wave-local: no s_barrier at all;
+//   * plans put the SMALL radix first (256 = 16x16 ... 4096 = 16x16x16, 8192 =
+//     32x16x16, 16384 = 32x32x16) so that every pass but the last has few distinct
+//     twiddles (LDS tables, stored as (c, d, -d, d)) and the last pass is always
+//     radix 16 with its 15 twiddles W_N^(r t) in registers;
+//   * a line is owned by T = nfft/E threads, E = 16 points per thread up to 4096
+//     points and 32 above (two LDS exchanges per line instead of three).  Up to
+//     1024 points T is at most one wave, so the LDS exchanges are wave-local: no
+//     s_barrier at all;
 //   * every sub-line walks its own run of consecutive lines, so a hop of SH*T
 //     samples is a shift of SH registers and each input byte is fetched once;
 //   * buffer addressing with scalar offsets, packed complex math, prefetch of the
@@ -20,29 +22,28 @@ namespace specgpu {
 
 namespace {
 
-constexpr int E = 16;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int L> struct Plan2;
-#define SPEC_PLAN2(L, NP, ...)                                                        \
+#define SPEC_PLAN2(L, EE, NP, ...)                                                    \
     template <> struct Plan2<L> {                                                     \
+        static constexpr int E = EE;                 /* points per thread */          \
         static constexpr int N = 1 << L, T = N / E, NPASS = NP;                       \
         static constexpr int radix[4] = {__VA_ARGS__};                                \
         static constexpr int WG = T <= 64 ? 256 : T; /* threads per workgroup */      \
         static constexpr int LPW = WG / T;           /* sub-lines per workgroup */    \
         static constexpr bool WAVE_LOCAL = T <= 64;  /* exchanges stay inside a wave */ \
-        static constexpr int LINE = N + N / 16 + (T < 32 ? 16 : 0); /* LDS elements per sub-line, pads included */ \
+        static constexpr int PADSH = E == 32 ? 5 : 4; /* one pad element per 2^PADSH (narrow-stride exchanges) */ \
+        static constexpr int LINE = N + (N >> PADSH) + (T < 32 ? 16 : 0); /* LDS elements per sub-line, pads included */ \
     };
-SPEC_PLAN2(6, 2, 4, 16, 1, 1)
-SPEC_PLAN2(7, 2, 8, 16, 1, 1)
-SPEC_PLAN2(8, 2, 16, 16, 1, 1)
-SPEC_PLAN2(9, 3, 2, 16, 16, 1)
-SPEC_PLAN2(10, 3, 4, 16, 16, 1)
-SPEC_PLAN2(11, 3, 8, 16, 16, 1)
-SPEC_PLAN2(12, 3, 16, 16, 16, 1)
-SPEC_PLAN2(13, 4, 2, 16, 16, 16)
-SPEC_PLAN2(14, 4, 4, 16, 16, 16)
+SPEC_PLAN2(8, 16, 2, 16, 16, 1, 1)
+SPEC_PLAN2(9, 16, 3, 2, 16, 16, 1)
+SPEC_PLAN2(10, 16, 3, 4, 16, 16, 1)
+SPEC_PLAN2(11, 16, 3, 8, 16, 16, 1)
+SPEC_PLAN2(12, 16, 3, 16, 16, 16, 1)
+SPEC_PLAN2(13, 32, 3, 32, 16, 16, 1)
+SPEC_PLAN2(14, 32, 3, 32, 32, 16, 1)
 #undef SPEC_PLAN2
 
 template <int L> constexpr int p2_P_of(int pass) {  // product of the radices before `pass`
@@ -114,40 +115,45 @@ template <> struct Raw2<K_CU8> {
 };
 
 // LDS layout of an exchange written with a stride narrower than 16 elements: one
-// pad element after every 16, index a -> a + (a >> 4).  The 16 lanes of a write
-// group then hit 16 different 8-byte slots, the stride-T read loses one cycle to
-// a single 2-way conflict (tools/lds_sim.py), and -- unlike an XOR swizzle -- every
-// address splits into a per-thread base plus a compile-time immediate, so an
-// exchange costs two address registers and no VALU work.
-constexpr int pad16(int a) { return a + (a >> 4); }
-__device__ __forceinline__ int pad16_rt(int a) { return a + (a >> 4); }
+// pad element after every 16 (32 for the 32-point first pass), index a -> a + (a >> PADSH).
+// The 16 lanes of a write group then hit 16 different 8-byte slots, the stride-T read
+// loses at most one cycle to a single 2-way conflict (tools/lds_sim.py), and -- unlike an
+// XOR swizzle -- every address splits into a per-thread base plus a compile-time
+// immediate, so an exchange costs two address registers and no VALU work.
+template <int SHIFT> constexpr int padn(int a) { return a + (a >> SHIFT); }
+template <int SHIFT> __device__ __forceinline__ int padn_rt(int a) { return a + (a >> SHIFT); }
 
 // One pass on the registers.  Middle passes take their twiddles from the LDS
 // table `tab` (entry (r, k) at r*P + k, as (c, d, -d, d)); the last pass from
-// the per-thread registers `twl`.
+// the per-thread registers `twl` (W_N^(r t); the second butterfly of an E = 32
+// thread sits T = N/32 further on: one more factor W_32^r, a compile-time constant).
 template <int L, int PASS>
-__device__ __forceinline__ void v2_pass(v2f (&v)[E], int t, const v4f *tab, v2f (&twl)[E]) {
+__device__ __forceinline__ void v2_pass(v2f (&v)[Plan2<L>::E], int t, const v4f *tab, v2f (&twl)[16]) {
     using PL = Plan2<L>;
-    constexpr int R = PL::radix[PASS], S = E / R, P = p2_P<L, PASS>();
+    constexpr int E = PL::E, R = PL::radix[PASS], S = E / R, P = p2_P<L, PASS>();
+    if constexpr (PASS > 0 && PASS < PL::NPASS - 1) {
+        // k = (t + s T) mod P is the same for every s (P divides T): one table row for all butterflies
+        static_assert(S == 1 || PL::T % P == 0, "butterflies of a thread share their twiddles");
+        const v4f *row = tab + p2_tab_off<L, PASS>() + (t & (P - 1));
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            const v4f q = row[r * P];
+#pragma unroll
+            for (int s = 0; s < S; ++s) v[s + r * S] = pk_cmul_pre(v[s + r * S], v2f{q.x, q.y}, v2f{q.z, q.w});
+        }
+    }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         v2f u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = v[s + r * S];
         if constexpr (PASS == PL::NPASS - 1) {
-            static_assert(R == 16 && S == 1, "last pass is one radix-16 butterfly");
+            static_assert(R == 16 && S <= 2, "last pass: radix-16 butterflies");
 #pragma unroll
             for (int r = 1; r < R; ++r) {
                 asm volatile("" : "+v"(twl[r]));  // keep (c, d) only: stops hipcc hoisting 15 derived (-d, d) pairs
                 u[r] = pk_cmul(u[r], twl[r]);
-            }
-        } else if constexpr (PASS > 0) {
-            const int k = (t + s * PL::T) & (P - 1);
-            const v4f *row = tab + p2_tab_off<L, PASS>() + k;
-#pragma unroll
-            for (int r = 1; r < R; ++r) {
-                const v4f q = row[r * P];
-                u[r] = pk_cmul_pre(u[r], v2f{q.x, q.y}, v2f{q.z, q.w});
+                if (s == 1) u[r] = r == 8 ? pk_mul_mi(u[r]) : pk_cmul_const(u[r], kW32[r][0], kW32[r][1]);
             }
         }
         pk_dft<R>(u);
@@ -158,38 +164,42 @@ __device__ __forceinline__ void v2_pass(v2f (&v)[E], int t, const v4f *tab, v2f 
 
 // registers -> LDS after PASS.  Index of output r of butterfly i = t + s T:
 //   hi*(R P) + r P + k,  k = i mod P, hi = i / P      (Stockham autosort)
-template <int L, int PASS> __device__ __forceinline__ void v2_store(const v2f (&v)[E], int t, v2f *lds) {
+template <int L, int PASS> __device__ __forceinline__ void v2_store(const v2f (&v)[Plan2<L>::E], int t, v2f *lds) {
     using PL = Plan2<L>;
-    constexpr int R = PL::radix[PASS], S = E / R, P = p2_P<L, PASS>();
+    constexpr int R = PL::radix[PASS], S = PL::E / R, P = p2_P<L, PASS>(), SH = PL::PADSH;
     if constexpr (P >= 16) {  // wide stride: plain layout is conflict free
-        static_assert(S == 1, "only the first pass has several butterflies per thread");
+        static_assert(S == 1 || PL::T % P == 0, "butterfly s sits s*T*R elements further on");
         v2f *base = lds + ((t & ~(P - 1)) * R + (t & (P - 1)));
-#pragma unroll
-        for (int r = 0; r < R; ++r) base[r * P] = v[r];
-    } else if constexpr (PASS == 0) {  // P == 1: a = i R + r, padded: pad(t R) + s*pad(T R) + r
-        static_assert((PL::T * R) % 16 == 0, "sub-line stride must be a multiple of 16 elements");
-        v2f *base = lds + pad16_rt(t * R);
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int r = 0; r < R; ++r) base[pad16(s * PL::T * R) + r] = v[s + r * S];
+            for (int r = 0; r < R; ++r) base[s * PL::T * R + r * P] = v[s + r * S];
+    } else if constexpr (PASS == 0) {  // P == 1: a = i R + r, padded: pad(t R) + s*pad(T R) + r
+        static_assert((PL::T * R) % (1 << SH) == 0 && R <= (1 << SH), "sub-line stride must be a multiple of the pad period");
+        v2f *base = lds + padn_rt<SH>(t * R);
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int r = 0; r < R; ++r) base[padn<SH>(s * PL::T * R) + r] = v[s + r * S];
     } else {  // 1 < P < 16, R = 16, S = 1: hi*(17 P) + k + pad(r P)
-        static_assert(S == 1 && R == 16, "middle passes are single radix-16 butterflies");
+        static_assert(S == 1 && R == 16 && SH == 4, "middle passes are single radix-16 butterflies");
         v2f *base = lds + ((t / P) * (17 * P) + (t & (P - 1)));
 #pragma unroll
-        for (int r = 0; r < R; ++r) base[pad16(r * P)] = v[r];
+        for (int r = 0; r < R; ++r) base[padn<4>(r * P)] = v[r];
     }
 }
 // LDS -> registers at stride T after the exchange written by PASS
-template <int L, int PASS> __device__ __forceinline__ void v2_load(v2f (&v)[E], int t, const v2f *lds) {
+template <int L, int PASS> __device__ __forceinline__ void v2_load(v2f (&v)[Plan2<L>::E], int t, const v2f *lds) {
     using PL = Plan2<L>;
+    constexpr int SH = PL::PADSH;
     if constexpr (p2_P<L, PASS>() >= 16) {
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = lds[t + m * PL::T];
+        for (int m = 0; m < PL::E; ++m) v[m] = lds[t + m * PL::T];
     } else {
-        const v2f *base = lds + (PL::T >= 16 ? pad16_rt(t) : t);
+        static_assert(PL::T < (1 << SH) || PL::T % (1 << SH) == 0, "pad(t + m T) = pad(t) + pad(m T)");
+        const v2f *base = lds + (PL::T >= (1 << SH) ? padn_rt<SH>(t) : t);
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = base[pad16(m * PL::T)];
+        for (int m = 0; m < PL::E; ++m) v[m] = base[padn<SH>(m * PL::T)];
     }
 }
 
@@ -219,7 +229,7 @@ template <int L> __device__ __forceinline__ void v2_sync() {
 }
 
 template <int L, int PASS = 0>
-__device__ __forceinline__ void v2_fft(v2f (&v)[E], int t, v2f *lds, const v4f *tab, v2f (&twl)[E]) {
+__device__ __forceinline__ void v2_fft(v2f (&v)[Plan2<L>::E], int t, v2f *lds, const v4f *tab, v2f (&twl)[16]) {
     using PL = Plan2<L>;
     v2_pass<L, PASS>(v, t, tab, twl);
     if constexpr (PASS + 1 < PL::NPASS) {
@@ -233,7 +243,7 @@ __device__ __forceinline__ void v2_fft(v2f (&v)[E], int t, v2f *lds, const v4f *
 
 // 20 log10(|X| + 1e-10) of the spectrum
 // scale * v (SS:80-81), one range test per thread
-template <bool DB> __device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, float (&d)[E]) {
+template <bool DB, int E> __device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, float (&d)[E]) {
     float p[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) p[m] = pk_norm(v[m]);
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     using PL = Plan2<L>;
     using RW = Raw2<KIND>;
     using raw_t = typename RW::type;
-    constexpr int BPS = RW::BPS, N = PL::N, T = PL::T;
+    constexpr int BPS = RW::BPS, N = PL::N, T = PL::T, E = PL::E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, t = tid % T, q = tid / T;
     v2f *lds = reinterpret_cast<v2f *>(smem) + (size_t)q * PL::LINE;
@@ -286,12 +296,12 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 
     // ---- one-time set-up: LDS twiddle tables of the middle passes, last-pass registers
     if constexpr (PL::NPASS > 2) fill_tables<L, 1>(tab, tw, tid);
-    v2f twl[E];
+    v2f twl[16];
 #pragma unroll
-    for (int r = 1; r < E; ++r) twl[r] = tw[(r * t) & (N - 1)];
-    // window values of this thread's 16 samples: registers, except for 16384 points (no room:
-    // re-read from the L2-resident table every line)
-    constexpr bool WIN_REGS = HAS_WIN && L < 14;
+    for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    // window values of this thread's samples: registers for 16-point threads, re-read from
+    // the L2-resident table every line for 32-point threads (no room)
+    constexpr bool WIN_REGS = HAS_WIN && E == 16;
     const float *win = static_cast<const float *>(a.win);
     float w[E];
     if constexpr (WIN_REGS) {
@@ -320,15 +330,9 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     // overlap shift: SH > 0 promises hop == SH * T, i.e. the line slides by SH registers
     constexpr int NEW = SH > 0 ? SH : E;
 
-    // 16384-point lines run in 1024-thread workgroups (128 VGPRs): no room to keep a line's raw
-    // samples across iterations, so they are fetched at the top of each line (overlap comes
-    // from L2) and the 16 resident waves cover the latency instead of a prefetch.
-    constexpr bool KEEP = L < 14;
     raw_t raw[E];
-    if constexpr (KEEP) {
 #pragma unroll
-        for (int m = 0; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, m * T * BPS);
-    }
+    for (int m = 0; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, m * T * BPS);
 
     float acc[E];
     if constexpr (MODE == 1) {
@@ -349,11 +353,6 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 
     auto do_line = [&](uint32_t line) {
         v2f v[E];
-        if constexpr (!KEEP) {
-            const int off = (int)(line * line_bytes);
-#pragma unroll
-            for (int m = 0; m < E; ++m) raw[m] = RW::template load<0>(src, voff, off + m * T * BPS);
-        }
         if constexpr (HAS_WIN && !WIN_REGS) {
             asm volatile("" : "+s"(win));  // keep the loads inside the loop (LICM would pin 16 VGPRs)
 #pragma unroll
@@ -365,15 +364,13 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 #pragma unroll
             for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};
         }
-        if constexpr (KEEP) {
-            if constexpr (SH > 0 && SH < E) {
+        if constexpr (SH > 0 && SH < E) {
 #pragma unroll
-                for (int m = 0; m < E - SH; ++m) raw[m] = raw[m + SH];
-            }
-            const int next_off = (int)((line + 1) * line_bytes);
-#pragma unroll
-            for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
+            for (int m = 0; m < E - SH; ++m) raw[m] = raw[m + SH];
         }
+        const int next_off = (int)((line + 1) * line_bytes);
+#pragma unroll
+        for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
 
         v2_fft<L>(v, t, lds, tab, twl);
 
@@ -384,8 +381,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
             }
         } else {
             float d[E];
-            if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true>(v, RW::SCALE, d);
-            else v2_epilogue<false>(v, RW::SCALE, d);
+            if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, E>(v, RW::SCALE, d);
+            else v2_epilogue<false, E>(v, RW::SCALE, d);
             const int out_off = (int)(line * (uint32_t)N * 4u);
 #pragma unroll
             for (int m = 0; m < E; ++m)  // (t + m T + N/2) mod N   (SS:78)
@@ -409,9 +406,13 @@ hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
     constexpr size_t lds = p2_lds_bytes<L>();
     // Minimum waves per SIMD asked of the register allocator, chosen so that the kernel does
     // not spill: about 104 VGPRs of FFT state + 32 (cf32) or 16 raw sample registers + 16 for a
-    // window + 16 for Welch sums.  1024-thread groups need 4 (128 VGPRs) to exist at all.
+    // window + 16 for Welch sums.  32-point threads (8192 / 16384 points) take the full 256.
     constexpr int NEED = 104 + (KIND == K_CF32 ? 32 : 16) + (HAS_WIN ? 16 : 0) + (MODE == 1 ? 16 : 0);
-    constexpr int WAVES_PER_SIMD = PL::WG == 1024 ? 4 : PL::WG == 512 ? 2 : NEED <= 120 ? 4 : NEED <= 152 ? 3 : 2;
+#ifdef SPEC_FORCE_OCC  // experiments only
+    constexpr int WAVES_PER_SIMD = PL::E == 32 ? 2 : SPEC_FORCE_OCC;
+#else
+    constexpr int WAVES_PER_SIMD = PL::E == 32 ? 2 : NEED <= 120 ? 4 : NEED <= 152 ? 3 : 2;
+#endif
     auto kern = v2_kernel<L, KIND, SH, HAS_WIN, MODE, BE, WAVES_PER_SIMD>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -422,12 +423,12 @@ hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Instantiation matrix: register-reuse variants for hop = 8 T (50 % overlap) in every format, for
-// hop = 4 T (75 %) in cf32 / ci16 and in every Welch kernel; big-endian files and every other hop
+// Instantiation matrix: register-reuse variants for hop = N/2 (50 % overlap) in every format, for
+// hop = N/4 (75 %) in cf32 / ci16 and in every Welch kernel; big-endian files and every other hop
 // take SH = 0 (the overlap then comes from L2).
 // Welch always multiplies by a window table (all ones for the rectangular window).
 template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hipStream_t s) {
-    constexpr int T = Plan2<L>::T;
+    constexpr int N = Plan2<L>::N, E = Plan2<L>::E;
     constexpr bool WIDE = KIND == K_CF32 || KIND == K_CI16;  // formats with a byte order
     if constexpr (WIDE) {  // big-endian files: one variant per mode (no register reuse), byte swap at decode
         if (a.be) {
@@ -436,14 +437,14 @@ template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hi
         }
     }
     if constexpr (MODE == 1) {
-        if (a.hop == 8 * T) return v2_launch1<L, KIND, 8, true, 1>(a, s);
-        if (a.hop == 4 * T) return v2_launch1<L, KIND, 4, true, 1>(a, s);
+        if (a.hop == N / 2) return v2_launch1<L, KIND, E / 2, true, 1>(a, s);
+        if (a.hop == N / 4) return v2_launch1<L, KIND, E / 4, true, 1>(a, s);
         return v2_launch1<L, KIND, 0, true, 1>(a, s);
     } else {
         const bool win = a.win != nullptr;
-        if (a.hop == 8 * T) return win ? v2_launch1<L, KIND, 8, true, 0>(a, s) : v2_launch1<L, KIND, 8, false, 0>(a, s);
+        if (a.hop == N / 2) return win ? v2_launch1<L, KIND, E / 2, true, 0>(a, s) : v2_launch1<L, KIND, E / 2, false, 0>(a, s);
         if constexpr (WIDE) {
-            if (a.hop == 4 * T) return win ? v2_launch1<L, KIND, 4, true, 0>(a, s) : v2_launch1<L, KIND, 4, false, 0>(a, s);
+            if (a.hop == N / 4) return win ? v2_launch1<L, KIND, E / 4, true, 0>(a, s) : v2_launch1<L, KIND, E / 4, false, 0>(a, s);
         }
         return win ? v2_launch1<L, KIND, 0, true, 0>(a, s) : v2_launch1<L, KIND, 0, false, 0>(a, s);
     }
@@ -461,8 +462,6 @@ template <int L, int MODE> hipError_t v2_launch_kind(const V2Args &a, int kind, 
 
 template <int MODE> hipError_t v2_launch_n(const V2Args &a, int log2n, int kind, hipStream_t s) {
     switch (log2n) {
-    case 6: return v2_launch_kind<6, MODE>(a, kind, s);
-    case 7: return v2_launch_kind<7, MODE>(a, kind, s);
     case 8: return v2_launch_kind<8, MODE>(a, kind, s);
     case 9: return v2_launch_kind<9, MODE>(a, kind, s);
     case 10: return v2_launch_kind<10, MODE>(a, kind, s);
