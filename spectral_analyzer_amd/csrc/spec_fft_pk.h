@@ -26,15 +26,17 @@ __device__ __forceinline__ v2f pk_swap(v2f a) { return __builtin_shufflevector(a
 __device__ __forceinline__ v2f pk_add_mi(v2f b, v2f a) { return __builtin_elementwise_fma(pk_swap(a), v2f{1.0f, -1.0f}, b); }
 __device__ __forceinline__ v2f pk_sub_mi(v2f b, v2f a) { return __builtin_elementwise_fma(pk_swap(a), v2f{-1.0f, 1.0f}, b); }
 
-// a * w for a run-time twiddle w = (c, d):  a*(c,c) + (a.y,a.x)*(-d,d)
+// a * w for a run-time twiddle w = (c, d):  (a.x, a.y)*(c, c) + (a.y, a.x)*(-d, d).
+// Two instructions: the swap is op_sel and the per-lane negation the neg_lo modifier of
+// v_pk_fma_f32 -- hipcc does not select neg_lo from IR (it builds (-d, d) with an extra
+// v_pk_mul or v_xor/v_mov), hence the asm; plain "v" operands, no side effects, so the
+// scheduler and the waitcnt insertion treat both like any other VALU instruction.
 __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
-    const v2f r = a * v2f{w.x, w.x};
-    const v2f nd = v2f{w.y, w.y} * v2f{-1.0f, 1.0f};
-    return __builtin_elementwise_fma(pk_swap(a), nd, r);
-}
-// the same with the second factor already arranged: wn = (-d, d)
-__device__ __forceinline__ v2f pk_cmul_pre(v2f a, v2f w, v2f wn) {
-    return __builtin_elementwise_fma(pk_swap(a), wn, a * v2f{w.x, w.x});
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(r));
+    return r;
 }
 // a * (c - i s) for compile-time constants
 __device__ __forceinline__ v2f pk_cmul_const(v2f a, float c, float d) {

@@ -3,7 +3,7 @@
 // ci8): spectrogram lines and Welch partial sums:
 //   * plans put the SMALL radix first (256 = 16x16 ... 4096 = 16x16x16, 8192 =
 //     32x16x16, 16384 = 32x32x16) so that every pass but the last has few distinct
-//     twiddles (LDS tables, stored as (c, d, -d, d)) and the last pass is always
+//     twiddles (LDS tables of (c, d)) and the last pass is always
 //     radix 16 with its 15 twiddles W_N^(r t) in registers;
 //   * a line is owned by T = nfft/E threads, E = 16 points per thread up to 4096
 //     points and 32 above (two LDS exchanges per line instead of three).  Up to
@@ -23,7 +23,6 @@ namespace specgpu {
 namespace {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <int L> struct Plan2;
 #define SPEC_PLAN2(L, EE, NP, ...)                                                    \
@@ -53,7 +52,7 @@ template <int L> constexpr int p2_P_of(int pass) {  // product of the radices be
 }
 template <int L, int PASS> constexpr int p2_P() { return p2_P_of<L>(PASS); }
 // LDS twiddle tables of the middle passes 1 .. NPASS-2: entry (r, k) of pass z at
-// off(z) + r*P_z + k, in v4f units
+// off(z) + r*P_z + k, in v2f units
 template <int L> constexpr int p2_tab_size(int pass) { return Plan2<L>::radix[pass] * p2_P_of<L>(pass); }
 template <int L> constexpr int p2_tab_off_of(int pass) {
     int o = 0;
@@ -63,7 +62,7 @@ template <int L> constexpr int p2_tab_off_of(int pass) {
 template <int L, int PASS> constexpr int p2_tab_off() { return p2_tab_off_of<L>(PASS); }
 template <int L> constexpr int p2_tab_entries() { return p2_tab_off_of<L>(Plan2<L>::NPASS - 1); }
 template <int L> constexpr size_t p2_lds_bytes() {
-    return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * 8 + (size_t)p2_tab_entries<L>() * 16;
+    return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * 8 + (size_t)p2_tab_entries<L>() * 8;
 }
 
 // ---- raw sample formats (SS:40-59); SCALE is folded into the epilogue -------------
@@ -124,22 +123,22 @@ template <int SHIFT> constexpr int padn(int a) { return a + (a >> SHIFT); }
 template <int SHIFT> __device__ __forceinline__ int padn_rt(int a) { return a + (a >> SHIFT); }
 
 // One pass on the registers.  Middle passes take their twiddles from the LDS
-// table `tab` (entry (r, k) at r*P + k, as (c, d, -d, d)); the last pass from
+// table `tab` (entry (r, k) at r*P + k); the last pass from
 // the per-thread registers `twl` (W_N^(r t); the second butterfly of an E = 32
 // thread sits T = N/32 further on: one more factor W_32^r, a compile-time constant).
 template <int L, int PASS>
-__device__ __forceinline__ void v2_pass(v2f (&v)[Plan2<L>::E], int t, const v4f *tab, v2f (&twl)[16]) {
+__device__ __forceinline__ void v2_pass(v2f (&v)[Plan2<L>::E], int t, const v2f *tab, v2f (&twl)[16]) {
     using PL = Plan2<L>;
     constexpr int E = PL::E, R = PL::radix[PASS], S = E / R, P = p2_P<L, PASS>();
     if constexpr (PASS > 0 && PASS < PL::NPASS - 1) {
         // k = (t + s T) mod P is the same for every s (P divides T): one table row for all butterflies
         static_assert(S == 1 || PL::T % P == 0, "butterflies of a thread share their twiddles");
-        const v4f *row = tab + p2_tab_off<L, PASS>() + (t & (P - 1));
+        const v2f *row = tab + p2_tab_off<L, PASS>() + (t & (P - 1));
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-            const v4f q = row[r * P];
+            const v2f q = row[r * P];
 #pragma unroll
-            for (int s = 0; s < S; ++s) v[s + r * S] = pk_cmul_pre(v[s + r * S], v2f{q.x, q.y}, v2f{q.z, q.w});
+            for (int s = 0; s < S; ++s) v[s + r * S] = pk_cmul(v[s + r * S], q);
         }
     }
 #pragma unroll
@@ -151,7 +150,6 @@ __device__ __forceinline__ void v2_pass(v2f (&v)[Plan2<L>::E], int t, const v4f 
             static_assert(R == 16 && S <= 2, "last pass: radix-16 butterflies");
 #pragma unroll
             for (int r = 1; r < R; ++r) {
-                asm volatile("" : "+v"(twl[r]));  // keep (c, d) only: stops hipcc hoisting 15 derived (-d, d) pairs
                 u[r] = pk_cmul(u[r], twl[r]);
                 if (s == 1) u[r] = r == 8 ? pk_mul_mi(u[r]) : pk_cmul_const(u[r], kW32[r][0], kW32[r][1]);
             }
@@ -203,14 +201,14 @@ template <int L, int PASS> __device__ __forceinline__ void v2_load(v2f (&v)[Plan
     }
 }
 
-// W_N^(r k STEP) for the (r, k) of one middle pass, as (c, d, -d, d)
-template <int L, int PASS> __device__ __forceinline__ void fill_tables(v4f *tab, const v2f *__restrict__ tw, int tid) {
+// W_N^(r k STEP) for the (r, k) of one middle pass
+template <int L, int PASS> __device__ __forceinline__ void fill_tables(v2f *tab, const v2f *__restrict__ tw, int tid) {
     using PL = Plan2<L>;
     if constexpr (PASS < PL::NPASS - 1) {
         constexpr int P = p2_P<L, PASS>(), R = PL::radix[PASS], STEP = PL::N / (P * R);
         for (int e = tid; e < R * P; e += PL::WG) {
             const v2f w0 = tw[(e / P) * (e % P) * STEP];
-            tab[p2_tab_off<L, PASS>() + e] = v4f{w0.x, w0.y, -w0.y, w0.y};
+            tab[p2_tab_off<L, PASS>() + e] = w0;
         }
         fill_tables<L, PASS + 1>(tab, tw, tid);
     }
@@ -229,21 +227,31 @@ template <int L> __device__ __forceinline__ void v2_sync() {
 }
 
 template <int L, int PASS = 0>
-__device__ __forceinline__ void v2_fft(v2f (&v)[Plan2<L>::E], int t, v2f *lds, const v4f *tab, v2f (&twl)[16]) {
+__device__ __forceinline__ void v2_fft(v2f (&v)[Plan2<L>::E], int t, v2f *lds, const v2f *tab, v2f (&twl)[16]) {
     using PL = Plan2<L>;
+#ifndef SPEC_ABL_NOFFT
     v2_pass<L, PASS>(v, t, tab, twl);
+#endif
     if constexpr (PASS + 1 < PL::NPASS) {
+#ifndef SPEC_ABL_NOLDS
+#ifndef SPEC_ABL_NOBAR
         v2_sync<L>();  // WAR: the previous exchange has been read by everyone
+#endif
         v2_store<L, PASS>(v, t, lds);
+#ifndef SPEC_ABL_NOBAR
         v2_sync<L>();
+#endif
         v2_load<L, PASS>(v, t, lds);
+#endif
         v2_fft<L, PASS + 1>(v, t, lds, tab, twl);
     }
 }
 
 // 20 log10(|X| + 1e-10) of the spectrum
 // scale * v (SS:80-81), one range test per thread
-template <bool DB, int E> __device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, float (&d)[E]) {
+// BOUNDED: the input format cannot overflow |X|^2 in fp32 (integer samples): no upper range test
+template <bool DB, bool BOUNDED, int E>
+__device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, float (&d)[E]) {
     float p[E];
 #pragma unroll
     for (int m = 0; m < E; ++m) p[m] = pk_norm(v[m]);
@@ -252,16 +260,25 @@ template <bool DB, int E> __device__ __forceinline__ void v2_epilogue(const v2f 
 #pragma unroll
         for (int m = 0; m < E; ++m) d[m] = p[m] * s2;
     } else {
-        float lo = fminf(fminf(p[0], p[1]), p[2]), hi = fmaxf(fmaxf(p[0], p[1]), p[2]);
+        float lo = fminf(fminf(p[0], p[1]), p[2]), hi = 0.0f;
 #pragma unroll
-        for (int m = 3; m + 1 < E; m += 2) { lo = fminf(fminf(lo, p[m]), p[m + 1]); hi = fmaxf(fmaxf(hi, p[m]), p[m + 1]); }
+        for (int m = 3; m + 1 < E; m += 2) lo = fminf(fminf(lo, p[m]), p[m + 1]);
         lo = fminf(lo, p[E - 1]);
-        hi = fmaxf(hi, p[E - 1]);
+        if constexpr (!BOUNDED) {
+            hi = fmaxf(fmaxf(p[0], p[1]), p[2]);
+#pragma unroll
+            for (int m = 3; m + 1 < E; m += 2) hi = fmaxf(fmaxf(hi, p[m]), p[m + 1]);
+            hi = fmaxf(hi, p[E - 1]);
+        }
         constexpr float k10 = 3.01029995663981195f;
         const float off = k10 * __log2f(s2);
-        if (lo * s2 > 1e-4f && hi < 1e37f) {
+        if (lo * s2 > 1e-4f && hi < 1e37f) {  // a NaN fails the first test
 #pragma unroll
-            for (int m = 0; m < E; ++m) d[m] = __builtin_fmaf(k10, __log2f(p[m]), off);
+            for (int m = 0; m < E; m += 2) {  // two bins per v_pk_fma_f32
+                const v2f r = __builtin_elementwise_fma(v2f{__log2f(p[m]), __log2f(p[m + 1])}, v2f{k10, k10}, v2f{off, off});
+                d[m] = r.x;
+                d[m + 1] = r.y;
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < E; ++m) d[m] = db20(cx<float>{v[m].x * scale, v[m].y * scale});
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, t = tid % T, q = tid / T;
     v2f *lds = reinterpret_cast<v2f *>(smem) + (size_t)q * PL::LINE;
-    v4f *tab = reinterpret_cast<v4f *>(smem + (size_t)PL::LPW * PL::LINE * 8);
+    v2f *tab = reinterpret_cast<v2f *>(smem + (size_t)PL::LPW * PL::LINE * 8);
     const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw);
 
     // ---- one-time set-up: LDS twiddle tables of the middle passes, last-pass registers
@@ -351,26 +368,36 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
     const uint32_t iters = PL::WAVE_LOCAL ? a.run : my_lines;  // whole-workgroup lines: LPW == 1
 
-    auto do_line = [&](uint32_t line) {
+    // 50 % overlap, cf32 spectrogram: the two register halves swap roles from one line to the next
+    // (two copies of the loop body) instead of being moved; every other variant shifts the
+    // registers down (the doubled body costs them 8-40 spilled VGPRs, more than the moves)
+    constexpr bool PINGPONG = SH * 2 == E && KIND == K_CF32 && !HAS_WIN && MODE == 0;
+    auto do_line = [&](uint32_t line, auto phase_tag) {
+        constexpr int PH = PINGPONG ? decltype(phase_tag)::value : 0;  // physical register of sample m: (m + PH*SH) mod E
         v2f v[E];
         if constexpr (HAS_WIN && !WIN_REGS) {
-            asm volatile("" : "+s"(win));  // keep the loads inside the loop (LICM would pin 16 VGPRs)
+            const float *wp = win;
+            asm volatile("" : "+s"(wp));  // keep the loads inside the loop (LICM would pin E VGPRs)
 #pragma unroll
-            for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
+            for (int m = 0; m < E; ++m) w[m] = wp[t + m * T];
         }
 #pragma unroll
-        for (int m = 0; m < E; ++m) v[m] = RW::dec(BE ? RW::swap(raw[m]) : raw[m]);  // SMH:87-91 byte order
+        for (int m = 0; m < E; ++m) {
+            const raw_t r = raw[(m + PH * SH) % E];
+            v[m] = RW::dec(BE ? RW::swap(r) : r);  // SMH:87-91 byte order
+        }
         if constexpr (HAS_WIN) {
 #pragma unroll
             for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};
         }
-        if constexpr (SH > 0 && SH < E) {
+        if constexpr (SH > 0 && SH < E && !PINGPONG) {
 #pragma unroll
             for (int m = 0; m < E - SH; ++m) raw[m] = raw[m + SH];
         }
         const int next_off = (int)((line + 1) * line_bytes);
 #pragma unroll
-        for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
+        for (int m = E - NEW; m < E; ++m)  // the next line is one phase further on
+            raw[PINGPONG ? (m + (1 - PH) * SH) % E : m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
 
         v2_fft<L>(v, t, lds, tab, twl);
 
@@ -381,16 +408,32 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
             }
         } else {
             float d[E];
-            if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, E>(v, RW::SCALE, d);
-            else v2_epilogue<false, E>(v, RW::SCALE, d);
+            constexpr bool BOUNDED = KIND != K_CF32;
+            if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, BOUNDED, E>(v, RW::SCALE, d);
+            else v2_epilogue<false, BOUNDED, E>(v, RW::SCALE, d);
             const int out_off = (int)(line * (uint32_t)N * 4u);
+#ifdef SPEC_ABL_NOSTORE
+            const bool do_store = d[0] == 123.456f;
+#else
+            constexpr bool do_store = true;
+#endif
+            if (do_store)
+            {
 #pragma unroll
-            for (int m = 0; m < E; ++m)  // (t + m T + N/2) mod N   (SS:78)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, ovoff,
-                                                      out_off + ((m + E / 2) & (E - 1)) * T * 4, ST_AUX);
+                for (int m = 0; m < E; ++m)  // (t + m T + N/2) mod N   (SS:78)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, ovoff,
+                                                          out_off + ((m + E / 2) & (E - 1)) * T * 4, ST_AUX);
+            }
         }
     };
-    for (uint32_t line = 0; line < iters; ++line) do_line(line);
+    if constexpr (PINGPONG) {
+        for (uint32_t line = 0; line < iters; line += 2) {
+            do_line(line, std::integral_constant<int, 0>{});
+            if (line + 1 < iters) do_line(line + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (uint32_t line = 0; line < iters; ++line) do_line(line, std::integral_constant<int, 0>{});
+    }
     if constexpr (MODE == 1) {
         // one fp32 slab per sub-line (zeros for idle ones); welch_finalize_kernel sums them in order
         float *slab = static_cast<float *>(a.out) + ((uint64_t)blockIdx.x * PL::LPW + q) * N;
