@@ -36,6 +36,10 @@ WORKLOADS = {
     "cfg2": ("cf32_le", 4096, 2048, 30, 0),   # BASELINE configs[1] -- the metric's config
     "cfg3": ("ci16_le", 4096, 2048, 30, 0),   # BASELINE configs[2] per-GPU share (8 G samples / 8)
     "cfg1": ("cf32_le", 1024, 512, 20, 0),    # BASELINE configs[0] sizes (plumbing case)
+    # development workloads (tools/ablate.sh): other line lengths at 50 % overlap
+    "n1024": ("cf32_le", 1024, 512, 30, 0),
+    "n8192": ("cf32_le", 8192, 4096, 30, 0),
+    "n16384": ("cf32_le", 16384, 8192, 30, 0),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 SEED = 0x5EC7A11A
@@ -158,6 +162,22 @@ def main() -> None:
                                       "(restated SpectralService.computeMagnitudes), %d pthreads"
                                       % (int(np.log2(cs)), cl, cores)}
 
+    # calibration outside the timed region ("calibrate with a device memcpy"): what a
+    # plain device-to-device copy of the output tile moves per second on THIS box, read + write
+    copy_gbps = None
+    if rank == 0 and n_lines * nfft * 4 >= (1 << 28):
+        dst = torch.empty_like(out)
+        for _ in range(3):
+            dst.copy_(out)
+        cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in cev:
+            a.record(stream)
+            dst.copy_(out)
+            b.record(stream)
+        torch.cuda.synchronize()
+        copy_gbps = 2.0 * out.numel() * 4 / (float(np.median([a.elapsed_time(b) for a, b in cev])) * 1e-3) / 1e9
+        del dst
+
     if rank == 0:
         lines_all = total_lines * args.steps
         value = lines_all / elapsed
@@ -181,7 +201,11 @@ def main() -> None:
                        "window": "rect" if window == 0 else "hann", "sharding": "time-slice x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "bytes_per_line": b_line, "lines_per_launch": n_lines},
+                         "kernel_ms": kern_ms, "bytes_per_line": b_line, "lines_per_launch": n_lines,
+                         # extras: reads only (the north star is phrased on reads) and the box's own copy rate
+                         "read_frac": n_lines * hop * bps / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "copy_GBps": copy_gbps,
+                         "frac_of_copy": (achieved / copy_gbps) if copy_gbps else None},
             "cpu_baseline": cpu_baseline,
             "parity_spot_check": checked,
         }

@@ -82,6 +82,9 @@ typedef enum {
 #define SPEC_FLAG_REF_CF64_ZERO 0x1u /* reproduce the reference defect: computeMagnitudes has
                                         no cf64 branch, so cf64 input yields -200 dB (SS:35-63) */
 
+#define SPEC_FLAG_REF_EDC_CF64_STRIDE8 0x4u /* reproduce the reference defect in the burst reader:
+                                        extractAndDownConvert strides cf64 by 8 bytes (EDC:60-67) */
+
 #define SPEC_FLAG_NULL_STREAM 0x2u   /* with hip_stream == NULL: launch on the device's default (null)
                                         stream instead of creating a private one */
 
@@ -207,6 +210,55 @@ spec_status spec_welch_psd(spec_ctx *ctx, const void *iq, int iq_on_device, uint
 spec_status spec_welch_psd_planar_f64(spec_ctx *ctx, const double *re, const double *im, uint64_t n_samples,
                                       uint32_t nfft, uint32_t hop, spec_window window, spec_psd_scaling scaling,
                                       double fs, int db, double *freq_out, float *psd_out);
+
+/* ---- burst analysis (the Analysis dialog) ---------- */
+
+typedef enum spec_downconv_mode {
+    SPEC_DC_FAST = 0, /* fast == true  (EDC:104-107): boxcar of `down` taps, then decimate */
+    SPEC_DC_LPF = 1   /* fast == false (EDC:108-113): low-pass FIR (8 down + 1 Hamming-sinc taps), then decimate */
+} spec_downconv_mode;
+
+/* Replaces: the reader half of
+ *   double[][] ExtractDownConvertService.extractAndDownConvert(MappedByteBuffer buffer,
+ *       long startSample, int count, String datatype, double freqOff, int down, boolean fast)
+ * (services/ExtractDownConvertService.java:54-97): `count` IQ pairs from sample start_sample of
+ * the recording, decoded to planar doubles re[count], im[count] with the reader's own table --
+ * ci16 /32768, cu8 (b - 127.5)/128, ci8 /128, cf64 doubles, everything else (SPEC_DT_UNKNOWN
+ * included) read as float pairs (EDC:94-96).  Bit-exact with the reference arithmetic.  Offsets
+ * are 64-bit (the reference casts to int, EDC:80-96).  A span that leaves the buffer is
+ * SPEC_ERANGE (the buffer getters throw IndexOutOfBoundsException). */
+spec_status spec_extract_iq(spec_ctx *ctx, const void *buffer, int buffer_on_device, uint64_t capacity,
+                            uint64_t start_sample, uint64_t count, spec_dtype dt, double *re, double *im,
+                            int out_on_device);
+
+/* Replaces: extractAndDownConvert as a whole (EDC:54-117): reader, frequency shift by freq_off
+ * cycles per input sample (the reference hands the resampler a sample rate of 1.0, EDC:106,112),
+ * filter, decimation by `down`.  Output: floor(count / down) samples, planar doubles.
+ * JDSP's Resampler is not in the reference tree, so the filter is this library's own
+ * specification (parity unpinned; oracle/spec_oracle.c so_down_convert):
+ *   xm[n] = x[n] exp(-2 pi i frac(freq_off n));  y[m] = sum_k h[k] xm[m down + c - k]
+ * with (h, c) = (boxcar 1/down of `down` taps, down - 1) or (Hamming-windowed sinc of 8 down + 1
+ * taps, cut-off 0.5/down, unit DC gain, 4 down); samples outside the burst are zero. */
+spec_status spec_down_convert(spec_ctx *ctx, const void *buffer, int buffer_on_device, uint64_t capacity,
+                              uint64_t start_sample, uint64_t count, spec_dtype dt, double freq_off,
+                              uint32_t down, spec_downconv_mode mode, double *re_out, double *im_out,
+                              int out_on_device);
+
+/* Replaces: the loop of AnalysisDialogController.updateMagnitudeChart
+ * (controllers/AnalysisDialogController.java:219-246): db_out[i] = 20 log10(v[i]),
+ * v[0] = hypot(re[0], im[0]), v[i] = alpha hypot(re[i], im[i]) + (1 - alpha) v[i-1].
+ * n values; the reference plots only the finite ones (ADC:239-242) -- left to the caller.
+ * The recurrence is evaluated as a parallel scan: equal to the serial loop to rounding. */
+spec_status spec_magnitude_trace(spec_ctx *ctx, const double *re, const double *im, int in_on_device,
+                                 uint64_t n, double alpha, double *db_out, int out_on_device);
+
+/* Replaces: the loop of AnalysisDialogController.updateFrequencyChart (ADC:256-284):
+ * hz_out[i-1] = center_freq + v[i], i = 1 .. n-1, where f[i] = wrap(atan2(im[i], re[i]) -
+ * atan2(im[i-1], re[i-1])) / (2 pi) * fs, v[1] = f[1], v[i] = alpha f[i] + (1 - alpha) v[i-1].
+ * n - 1 values. */
+spec_status spec_inst_freq_trace(spec_ctx *ctx, const double *re, const double *im, int in_on_device,
+                                 uint64_t n, double alpha, double fs, double center_freq,
+                                 double *hz_out, int out_on_device);
 
 /* ---- synthetic input (bench / tests) -------------------------- */
 

@@ -396,6 +396,133 @@ int so_synth_iq(uint8_t *out, const char *dt, uint64_t seed,
     return 0;
 }
 
+/* ==========================================================================
+ * the burst-analysis chain behind the Analysis dialog
+ * ========================================================================== */
+
+/* ExtractDownConvertService.java:60-97, the reader: `count` samples from sample
+ * start_sample into planar doubles.  Differences from SS:40-65, restated as they are:
+ * any datatype that is not ci16/cu8/ci8/cf64 reads as float pairs (EDC:94-96, no
+ * zero branch), and the reference strides cf64 by 8 bytes (EDC:60-67 has no cf64
+ * case: sample i's Q is sample i+1's I) -- ref_cf64_stride8 != 0 reproduces that,
+ * 0 uses the 16 bytes of Global.java:67-79.  Offsets are 64-bit here (the
+ * reference casts to int, EDC:80-96).  -1: span outside the buffer. */
+int so_extract_iq(const uint8_t *buf, uint64_t capacity, uint64_t start_sample, uint64_t count,
+                  const char *dt, int ref_cf64_stride8, double *re, double *im) {
+    const int be = so_is_big_endian(dt);
+    int kind = K_CF32, bps = 8, width = 8;
+    if (starts_with(dt, "ci16")) { kind = K_CI16; bps = 4; width = 4; }
+    else if (starts_with(dt, "cu8")) { kind = K_CU8; bps = 2; width = 2; }
+    else if (starts_with(dt, "ci8")) { kind = K_CI8; bps = 2; width = 2; }
+    else if (starts_with(dt, "cf64")) { kind = K_CF64; bps = ref_cf64_stride8 ? 8 : 16; width = 16; }
+    if (count == 0) return 0;
+    const uint64_t start_byte = start_sample * (uint64_t)bps;
+    if (start_byte + (count - 1) * (uint64_t)bps + (uint64_t)width > capacity) return -1;
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint8_t *p = buf + start_byte + i * (uint64_t)bps;
+        switch (kind) {
+        case K_CF64: re[i] = get_f64(p, be); im[i] = get_f64(p + 8, be); break;           /* EDC:79-81 */
+        case K_CI16: re[i] = (double)(int16_t)get_u16(p, be) / 32768.0;                   /* EDC:83-85 */
+                     im[i] = (double)(int16_t)get_u16(p + 2, be) / 32768.0; break;
+        case K_CU8:  re[i] = ((double)p[0] - 127.5) / 128; im[i] = ((double)p[1] - 127.5) / 128; break; /* EDC:86-90 */
+        case K_CI8:  re[i] = (double)(int8_t)p[0] / 128.0; im[i] = (double)(int8_t)p[1] / 128.0; break; /* EDC:91-93 */
+        default:     re[i] = get_f32(p, be); im[i] = get_f32(p + 4, be);                  /* EDC:94-96 */
+        }
+    }
+    return 0;
+}
+
+/* Down-converter taps of the build's own specification (JDSP v1.3.1 Resampler is
+ * absent from the reference tree: parity unpinned).  mode 0 ("fast", EDC:104-107: "moving
+ * average filter prior to decimation"): K = down boxcar taps 1/down, alignment c = down-1.
+ * mode 1 ("conventional", EDC:108-113: low-pass then decimate): K = 8 down + 1 Hamming-
+ * windowed sinc taps, cut-off 0.5/down cycles per sample, unit DC gain, c = 4 down. */
+uint32_t so_down_convert_taps(uint32_t down, int mode, double *h /* may be NULL */, uint32_t *centre) {
+    const uint32_t K = mode == 0 ? down : 8 * down + 1;
+    if (centre) *centre = mode == 0 ? down - 1 : 4 * down;
+    if (!h) return K;
+    if (mode == 0) {
+        for (uint32_t k = 0; k < K; ++k) h[k] = 1.0 / (double)down;
+        return K;
+    }
+    const double c = 4.0 * down;
+    double sum = 0.0;
+    for (uint32_t k = 0; k < K; ++k) {
+        const double x = ((double)k - c) / (double)down;
+        const double sinc = x == 0.0 ? 1.0 : sin(M_PI * x) / (M_PI * x);
+        h[k] = sinc * (0.54 - 0.46 * cos(2.0 * M_PI * (double)k / (double)(K - 1)));
+        sum += h[k];
+    }
+    for (uint32_t k = 0; k < K; ++k) h[k] /= sum;
+    return K;
+}
+
+uint64_t so_down_convert_len(uint64_t n, uint32_t down) { return down ? n / down : 0; }
+
+/* xm[n] = x[n] exp(-2 pi i frac(freq_off n))  (freq_off in cycles per input sample: the
+ * reference passes a sample rate of 1.0, EDC:106,112);  y[m] = sum_k h[k] xm[m down + c - k],
+ * samples outside [0, n) are zero;  m < floor(n / down). */
+int so_down_convert(const double *re, const double *im, uint64_t n, double freq_off, uint32_t down,
+                    int mode, double *ore, double *oim) {
+    if (down == 0 || (mode != 0 && mode != 1)) return -1;
+    uint32_t c;
+    const uint32_t K = so_down_convert_taps(down, mode, NULL, &c);
+    double *h = (double *)malloc(sizeof(double) * K);
+    double *mr = (double *)malloc(sizeof(double) * (n ? n : 1)), *mi = (double *)malloc(sizeof(double) * (n ? n : 1));
+    if (!h || !mr || !mi) { free(h); free(mr); free(mi); return -1; }
+    so_down_convert_taps(down, mode, h, &c);
+    for (uint64_t i = 0; i < n; ++i) {
+        double t = freq_off * (double)i;
+        t -= floor(t);
+        const double a = 2.0 * M_PI * t, cs = cos(a), sn = sin(a);
+        mr[i] = re[i] * cs + im[i] * sn;  /* (re + i im)(cs - i sn) */
+        mi[i] = im[i] * cs - re[i] * sn;
+    }
+    const uint64_t n_out = n / down;
+    for (uint64_t m = 0; m < n_out; ++m) {
+        double ar = 0.0, ai = 0.0;
+        for (uint32_t k = 0; k < K; ++k) {
+            const int64_t idx = (int64_t)(m * down) + (int64_t)c - (int64_t)k;
+            if (idx < 0 || (uint64_t)idx >= n) continue;
+            ar += h[k] * mr[idx];
+            ai += h[k] * mi[idx];
+        }
+        ore[m] = ar;
+        oim[m] = ai;
+    }
+    free(h); free(mr); free(mi);
+    return 0;
+}
+
+/* AnalysisDialogController.java:219-246 updateMagnitudeChart: hypot, exponential moving
+ * average seeded with the first value, 20 log10.  Every point is returned; the reference
+ * plots only the finite ones (ADC:239-242). */
+void so_magnitude_trace(const double *re, const double *im, uint64_t n, double alpha, double *db) {
+    double v = 0.0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const double a = hypot(re[i], im[i]);
+        v = i == 0 ? a : alpha * a + (1 - alpha) * v;
+        db[i] = 20 * log10(v);
+    }
+}
+
+/* AnalysisDialogController.java:256-284 updateFrequencyChart: phase difference of
+ * neighbouring samples wrapped to [-pi, pi], scaled to Hz, EMA seeded at i == 1, plus the
+ * centre frequency.  out has n - 1 values (i = 1 .. n-1). */
+void so_inst_freq_trace(const double *re, const double *im, uint64_t n, double alpha, double fs,
+                        double center_freq, double *out) {
+    double v = 0.0;
+    for (uint64_t i = 1; i < n; ++i) {
+        double d = atan2(im[i], re[i]) - atan2(im[i - 1], re[i - 1]);
+        if (d > M_PI) d -= 2 * M_PI;
+        else if (d < -M_PI) d += 2 * M_PI;
+        const double f = (d / (2 * M_PI)) * fs;
+        v = i == 1 ? f : (alpha * f) + (1 - alpha) * v;
+        out[i - 1] = v + center_freq;
+    }
+}
+
+
 /* ---------------- timed driver for the CPU baseline ---------------- */
 typedef struct {
     const uint8_t *buf; uint64_t capacity; const char *dt;

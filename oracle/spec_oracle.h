@@ -22,6 +22,8 @@
  *   controllers/MainController.java:980-999     line loop, range test, -150 fill
  *   controllers/MainController.java:1270-1283   dB/Hz display normalisation
  *   controllers/AnalysisDialogController.java:303-313   PSD call shape
+ *   controllers/AnalysisDialogController.java:219-284   magnitude / instantaneous-frequency traces
+ *   services/ExtractDownConvertService.java:54-117      burst reader + down-converter call
  * Third-party arithmetic (not in the reference tree, restated from the
  * published definitions):
  *   org.apache.commons:commons-math3:3.6.1  FastFourierTransformer(STANDARD).
@@ -116,6 +118,28 @@ void so_render_spectrogram(const double *waterfall, uint32_t width, uint32_t nff
  * the byte layout of `datatype` (honours _be). */
 int so_synth_iq(uint8_t *out, const char *datatype, uint64_t seed,
                 uint64_t first_sample, uint64_t n_samples);
+
+/* ---- the Analysis dialog's burst chain ------------------------
+ * services/ExtractDownConvertService.java:54-117, controllers/AnalysisDialogController.java:219-284 */
+
+/* EDC:60-97 reader: planar doubles; ref_cf64_stride8 reproduces the reference's 8-byte cf64
+ * stride (EDC:60-67), 0 = 16 bytes.  Unknown datatypes read as cf32 (EDC:94-96). -1: out of range. */
+int so_extract_iq(const uint8_t *buf, uint64_t capacity, uint64_t start_sample, uint64_t count,
+                  const char *datatype, int ref_cf64_stride8, double *re, double *im);
+
+/* Build-defined down-converter (JDSP Resampler absent: parity unpinned; see spec_oracle.c).
+ * mode 0 = boxcar ("fast", EDC:104-107), 1 = windowed-sinc low-pass (EDC:108-113).
+ * so_down_convert_taps returns the tap count (h may be NULL) and the alignment index. */
+uint32_t so_down_convert_taps(uint32_t down, int mode, double *h, uint32_t *centre);
+uint64_t so_down_convert_len(uint64_t n, uint32_t down);
+int so_down_convert(const double *re, const double *im, uint64_t n, double freq_off, uint32_t down,
+                    int mode, double *re_out, double *im_out);
+
+/* ADC:219-246: db[i] = 20 log10(EMA_alpha(hypot(re, im)))[i], n values */
+void so_magnitude_trace(const double *re, const double *im, uint64_t n, double alpha, double *db);
+/* ADC:256-284: EMA_alpha(wrapped phase step / 2 pi * fs) + center_freq, n - 1 values */
+void so_inst_freq_trace(const double *re, const double *im, uint64_t n, double alpha, double fs,
+                        double center_freq, double *out);
 
 /* Timed driver for bench.py's cpu_baseline leg: runs so_waterfall over the
  * buffer with `threads` pthreads splitting the lines; returns seconds. */

@@ -68,6 +68,12 @@ def lib() -> C.CDLL:
         L.so_time_waterfall.argtypes = [u8p, C.c_uint64, C.c_char_p, C.c_uint32, C.c_uint32,
                                         C.c_uint64, C.c_int, C.c_int, dp]
         L.so_time_waterfall.restype = C.c_double
+        L.so_extract_iq.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, dp, dp]
+        L.so_down_convert_taps.argtypes = [C.c_uint32, C.c_int, dp, C.c_void_p]
+        L.so_down_convert_taps.restype = C.c_uint32
+        L.so_down_convert.argtypes = [dp, dp, C.c_uint64, C.c_double, C.c_uint32, C.c_int, dp, dp]
+        L.so_magnitude_trace.argtypes = [dp, dp, C.c_uint64, C.c_double, dp]
+        L.so_inst_freq_trace.argtypes = [dp, dp, C.c_uint64, C.c_double, C.c_double, C.c_double, dp]
         _lib = L
     return _lib
 
@@ -166,6 +172,53 @@ def time_waterfall(buf, datatype: str, nfft: int, hop: int, n_lines: int, window
     t = lib().so_time_waterfall(b.ctypes.data, b.size, datatype.encode(), nfft, hop, n_lines,
                                 window, threads, C.addressof(cs))
     return float(t), float(cs.value)
+
+
+def extract_iq(buf, start_sample: int, count: int, datatype: str, ref_cf64_stride8: bool = False):
+    """EDC:60-97 reader -> (re, im) float64 arrays."""
+    b = _bytes_view(buf)
+    re, im = np.empty(count, dtype=np.float64), np.empty(count, dtype=np.float64)
+    rc = lib().so_extract_iq(b.ctypes.data, b.size, start_sample, count, datatype.encode(), int(ref_cf64_stride8),
+                             re.ctypes.data, im.ctypes.data)
+    if rc:
+        raise IndexError("IndexOutOfBoundsException")
+    return re, im
+
+
+def down_convert_taps(down: int, mode: int):
+    c = C.c_uint32(0)
+    k = lib().so_down_convert_taps(down, mode, None, C.addressof(c))
+    h = np.empty(k, dtype=np.float64)
+    lib().so_down_convert_taps(down, mode, h.ctypes.data, C.addressof(c))
+    return h, int(c.value)
+
+
+def down_convert(re, im, freq_off: float, down: int, mode: int = 0):
+    re = np.ascontiguousarray(re, dtype=np.float64)
+    im = np.ascontiguousarray(im, dtype=np.float64)
+    n_out = len(re) // down if down else 0
+    ore, oim = np.empty(n_out, dtype=np.float64), np.empty(n_out, dtype=np.float64)
+    rc = lib().so_down_convert(re.ctypes.data, im.ctypes.data, len(re), freq_off, down, mode,
+                               ore.ctypes.data, oim.ctypes.data)
+    if rc:
+        raise ValueError("bad down-converter arguments")
+    return ore, oim
+
+
+def magnitude_trace(re, im, alpha: float) -> np.ndarray:
+    re = np.ascontiguousarray(re, dtype=np.float64)
+    im = np.ascontiguousarray(im, dtype=np.float64)
+    out = np.empty(len(re), dtype=np.float64)
+    lib().so_magnitude_trace(re.ctypes.data, im.ctypes.data, len(re), alpha, out.ctypes.data)
+    return out
+
+
+def inst_freq_trace(re, im, alpha: float, fs: float, center_freq: float = 0.0) -> np.ndarray:
+    re = np.ascontiguousarray(re, dtype=np.float64)
+    im = np.ascontiguousarray(im, dtype=np.float64)
+    out = np.empty(max(len(re) - 1, 0), dtype=np.float64)
+    lib().so_inst_freq_trace(re.ctypes.data, im.ctypes.data, len(re), alpha, fs, center_freq, out.ctypes.data)
+    return out
 
 
 # --------------------------------------------------------------------------

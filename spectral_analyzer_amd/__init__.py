@@ -10,6 +10,7 @@ from ._lib import (CMAP_GRAYSCALE, CMAP_HEATMAP, DT_CF32_BE, DT_CF32_LE, DT_CF64
                    PSD_DENSITY, PSD_SPECTRUM, WIN_HANN, WIN_RECT)
 from .spectral_service import SpectralService, bytes_per_sample, dtype_from_sigmf  # noqa: F401
 
+from .extract_down_convert_service import ExtractDownConvertService  # noqa: F401,E402
 from . import sigmf  # noqa: F401,E402
 
-__all__ = ["SpectralService", "bytes_per_sample", "dtype_from_sigmf", "sigmf"]
+__all__ = ["SpectralService", "ExtractDownConvertService", "bytes_per_sample", "dtype_from_sigmf", "sigmf"]

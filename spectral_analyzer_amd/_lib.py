@@ -24,6 +24,8 @@ PSD_DENSITY, PSD_SPECTRUM = 0, 1
 CMAP_GRAYSCALE, CMAP_HEATMAP = 0, 1
 FLAG_REF_CF64_ZERO = 0x1
 FLAG_NULL_STREAM = 0x2
+FLAG_REF_EDC_CF64_STRIDE8 = 0x4
+DC_FAST, DC_LPF = 0, 1
 
 # every symbol include/specgpu.h declares, with its ctypes signature
 _u64, _u32, _i32, _vp, _cp, _dbl = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_char_p, C.c_double
@@ -46,6 +48,10 @@ SIGNATURES = {
     "spec_waterfall_render": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u32, _i32, _u32, _dbl, _dbl,
                                      _dbl, _i32, _vp, _i32]),
     "spec_welch_psd_planar_f64": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "spec_extract_iq": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _i32, _vp, _vp, _i32]),
+    "spec_down_convert": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _i32, _dbl, _u32, _i32, _vp, _vp, _i32]),
+    "spec_magnitude_trace": (_i32, [_vp, _vp, _vp, _i32, _u64, _dbl, _vp, _i32]),
+    "spec_inst_freq_trace": (_i32, [_vp, _vp, _vp, _i32, _u64, _dbl, _dbl, _dbl, _vp, _i32]),
     "spec_synth_iq": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64]),
 }
 

@@ -1,0 +1,215 @@
+// spec_burst.hip -- the Analysis dialog's burst chain, fp64:
+//   reader + mixer   ExtractDownConvertService.java:60-97 (+ the frequency shift of EDC:104-113)
+//   FIR + decimate   the build's own down-converter specification (JDSP Resampler is absent)
+//   magnitude trace  AnalysisDialogController.java:219-246   hypot -> EMA -> 20 log10
+//   frequency trace  AnalysisDialogController.java:256-284   phase step -> wrap -> Hz -> EMA
+// The exponential moving average v[i] = alpha x[i] + (1 - alpha) v[i-1] is a first-order linear
+// recurrence: every element is the affine map v -> a v + b, maps compose associatively, so the
+// traces are three small kernels (tile aggregates, carries, apply) instead of one serial loop.
+#include "spec_fft.h"
+#include "spec_internal.h"
+
+namespace specgpu {
+
+namespace {
+
+constexpr int TR_THREADS = 256, TR_ITEMS = 8, TR_TILE = TR_THREADS * TR_ITEMS;
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- reader (EDC:60-97) + optional mixer ------------------------------------------------------
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t *p, bool be) {
+    const uint64_t u = *reinterpret_cast<const uint64_t *>(p);
+    return be ? __builtin_bswap64(u) : u;
+}
+
+__global__ __launch_bounds__(256) void extract_mix_kernel(const uint8_t *__restrict__ raw, int kind, int be,
+                                                          uint32_t stride, uint64_t count, double freq_off,
+                                                          double *__restrict__ re, double *__restrict__ im) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const uint8_t *p = raw + i * stride;
+        double x, y;
+        if (kind == K_CF64) {  // two 8-byte loads: the reference's 8-byte stride (EDC:60-67) is not 16-byte aligned
+            x = __longlong_as_double((long long)ld_u64(p, be));
+            y = __longlong_as_double((long long)ld_u64(p + 8, be));
+        } else {
+            const cx<double> z = decode_sample<double>(p, kind, be);
+            x = z.x;
+            y = z.y;
+        }
+        if (freq_off != 0.0) {  // x exp(-2 pi i frac(freq_off n))
+            // the phase is the ROUNDED product minus its floor (the serial definition); the empty asm keeps
+            // the backend (-ffp-contract=fast) from fusing the multiply into the subtraction
+            double t = freq_off * (double)i;
+            asm volatile("" : "+v"(t));
+            t -= floor(t);
+            const double a = 2.0 * kPi * t, cs = cos(a), sn = sin(a);
+            const double xr = x * cs + y * sn, xi = y * cs - x * sn;
+            x = xr;
+            y = xi;
+        }
+        re[i] = x;
+        im[i] = y;
+    }
+}
+
+// y[m] = sum_k h[k] xm[m down + c - k], zero outside [0, n)
+__global__ __launch_bounds__(256) void fir_decim_kernel(const double *__restrict__ mr, const double *__restrict__ mi,
+                                                        uint64_t n, const double *__restrict__ h, uint32_t K,
+                                                        uint32_t c, uint32_t down, double *__restrict__ ore,
+                                                        double *__restrict__ oim, uint64_t n_out) {
+    for (uint64_t m = (uint64_t)blockIdx.x * 256 + threadIdx.x; m < n_out; m += (uint64_t)gridDim.x * 256) {
+        const int64_t top = (int64_t)(m * down) + (int64_t)c;  // index read by tap 0
+        double ar = 0.0, ai = 0.0;
+        for (uint32_t k = 0; k < K; ++k) {
+            const int64_t idx = top - (int64_t)k;
+            if (idx < 0 || (uint64_t)idx >= n) continue;
+            ar += h[k] * mr[idx];
+            ai += h[k] * mi[idx];
+        }
+        ore[m] = ar;
+        oim[m] = ai;
+    }
+}
+
+// ---- traces -------------------------------------------------------------------------------------
+struct Aff { double a, b; };  // v -> a v + b
+__device__ __forceinline__ Aff then(Aff first, Aff second) { return {first.a * second.a, second.a * first.b + second.b}; }
+
+// element j of the trace's input sequence
+template <int KIND_TRACE>
+__device__ __forceinline__ double trace_input(const double *__restrict__ re, const double *__restrict__ im,
+                                              uint64_t j, double fs) {
+    if constexpr (KIND_TRACE == 0) {
+        return hypot(re[j], im[j]);  // ADC:230
+    } else {                         // ADC:265-276, output j is sample i = j + 1
+        double d = atan2(im[j + 1], re[j + 1]) - atan2(im[j], re[j]);
+        if (d > kPi) d -= 2 * kPi;
+        else if (d < -kPi) d += 2 * kPi;
+        return (d / (2 * kPi)) * fs;
+    }
+}
+
+// inclusive scan of the 256 thread aggregates of a workgroup; returns this thread's EXCLUSIVE prefix and
+// leaves the workgroup total in *total
+__device__ __forceinline__ Aff wg_scan(Aff mine, Aff *lds, Aff *total) {
+    const int t = threadIdx.x;
+    lds[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < TR_THREADS; off <<= 1) {
+        Aff prev{1.0, 0.0};
+        const bool has = t >= off;
+        if (has) prev = lds[t - off];
+        __syncthreads();
+        if (has) lds[t] = then(prev, lds[t]);
+        __syncthreads();
+    }
+    *total = lds[TR_THREADS - 1];
+    const Aff excl = t == 0 ? Aff{1.0, 0.0} : lds[t - 1];
+    __syncthreads();
+    return excl;
+}
+
+// FINAL == false: per-tile aggregate map -> tile_aff[tile].
+// FINAL == true: carry[tile] (value at the end of the previous tile) in, trace values out.
+template <int KIND_TRACE, bool FINAL>
+__global__ __launch_bounds__(TR_THREADS) void trace_kernel(const double *__restrict__ re, const double *__restrict__ im,
+                                                           uint64_t n_out, double alpha, double fs, double add,
+                                                           Aff *__restrict__ tile_aff, const double *__restrict__ carry,
+                                                           double *__restrict__ out) {
+    __shared__ Aff lds[TR_THREADS];
+    const uint64_t j0 = (uint64_t)blockIdx.x * TR_TILE + (uint64_t)threadIdx.x * TR_ITEMS;
+    double x[TR_ITEMS];
+    Aff agg{1.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < TR_ITEMS; ++k) {
+        const uint64_t j = j0 + k;
+        if (j < n_out) {
+            x[k] = trace_input<KIND_TRACE>(re, im, j, fs);
+            agg = then(agg, j == 0 ? Aff{0.0, x[k]} : Aff{1 - alpha, alpha * x[k]});  // ADC:233-237 / 277-281
+        } else {
+            x[k] = 0.0;
+        }
+    }
+    Aff total;
+    const Aff excl = wg_scan(agg, lds, &total);
+    if constexpr (!FINAL) {
+        if (threadIdx.x == 0) tile_aff[blockIdx.x] = total;
+    } else {
+        double v = excl.a * carry[blockIdx.x] + excl.b;  // value just before this thread's first element
+#pragma unroll
+        for (int k = 0; k < TR_ITEMS; ++k) {
+            const uint64_t j = j0 + k;
+            if (j < n_out) {
+                v = j == 0 ? x[k] : alpha * x[k] + (1 - alpha) * v;
+                out[j] = KIND_TRACE == 0 ? 20 * log10(v) : v + add;  // ADC:239 / ADC:282
+            }
+        }
+    }
+}
+
+// one workgroup: carry[tile] = value at the end of tile - 1 (0 for tile 0, never used: element 0 resets)
+__global__ __launch_bounds__(TR_THREADS) void trace_carry_kernel(const Aff *__restrict__ tile_aff, uint32_t n_tiles,
+                                                                 double *__restrict__ carry) {
+    __shared__ Aff lds[TR_THREADS];
+    const uint32_t per = (n_tiles + TR_THREADS - 1) / TR_THREADS;
+    const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    Aff agg{1.0, 0.0};
+    for (uint32_t i = t0; i < t1; ++i) agg = then(agg, tile_aff[i]);
+    Aff total;
+    Aff run = wg_scan(agg, lds, &total);
+    // every prefix that contains element 0 has a == 0, so its b is the value itself
+    for (uint32_t i = t0; i < t1; ++i) {
+        carry[i] = run.b;
+        run = then(run, tile_aff[i]);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_extract_mix(const uint8_t *raw, int kind, int be, uint32_t stride, uint64_t count, double freq_off,
+                              double *re, double *im, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    const uint64_t wgs = (count + 255) / 256;
+    hipLaunchKernelGGL(extract_mix_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(256), 0, s, raw, kind, be,
+                       stride, count, freq_off, re, im);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_decim(const double *mr, const double *mi, uint64_t n, const double *h, uint32_t K, uint32_t c,
+                            uint32_t down, double *ore, double *oim, uint64_t n_out, hipStream_t s) {
+    if (n_out == 0) return hipSuccess;
+    const uint64_t wgs = (n_out + 255) / 256;
+    hipLaunchKernelGGL(fir_decim_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(256), 0, s, mr, mi, n, h, K, c,
+                       down, ore, oim, n_out);
+    return hipGetLastError();
+}
+
+size_t trace_scratch_bytes(uint64_t n_out) {
+    const uint64_t tiles = (n_out + TR_TILE - 1) / TR_TILE;
+    return (size_t)tiles * (sizeof(Aff) + sizeof(double));
+}
+
+hipError_t launch_trace(int kind_trace, const double *re, const double *im, uint64_t n_out, double alpha, double fs,
+                        double add, void *scratch, double *out, hipStream_t s) {
+    if (n_out == 0) return hipSuccess;
+    const uint64_t tiles = (n_out + TR_TILE - 1) / TR_TILE;
+    if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    Aff *tile_aff = static_cast<Aff *>(scratch);
+    double *carry = reinterpret_cast<double *>(tile_aff + tiles);
+    if (kind_trace == 0) {
+        hipLaunchKernelGGL((trace_kernel<0, false>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
+                           add, tile_aff, nullptr, nullptr);
+        hipLaunchKernelGGL(trace_carry_kernel, dim3(1), dim3(TR_THREADS), 0, s, tile_aff, (uint32_t)tiles, carry);
+        hipLaunchKernelGGL((trace_kernel<0, true>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
+                           add, tile_aff, carry, out);
+    } else {
+        hipLaunchKernelGGL((trace_kernel<1, false>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
+                           add, tile_aff, nullptr, nullptr);
+        hipLaunchKernelGGL(trace_carry_kernel, dim3(1), dim3(TR_THREADS), 0, s, tile_aff, (uint32_t)tiles, carry);
+        hipLaunchKernelGGL((trace_kernel<1, true>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
+                           add, tile_aff, carry, out);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace specgpu

@@ -696,6 +696,167 @@ spec_status spec_waterfall_render(spec_ctx *c, const void *iq, int iq_on_device,
                                    max_db, colormap, bgra_out, out_on_device);
 }
 
+// ---- burst analysis ---------------------------------------------------
+
+// reader geometry of EDC:60-96: decode kind, byte stride between samples, bytes one sample touches
+static void edc_layout(const spec_ctx *c, spec_dtype dt, int *kind, uint32_t *stride, uint32_t *width) {
+    switch (dt) {
+    case SPEC_DT_CI16_LE: case SPEC_DT_CI16_BE: *kind = K_CI16; *stride = *width = 4; break;
+    case SPEC_DT_CU8: *kind = K_CU8; *stride = *width = 2; break;
+    case SPEC_DT_CI8: *kind = K_CI8; *stride = *width = 2; break;
+    case SPEC_DT_CF64_LE: case SPEC_DT_CF64_BE:
+        *kind = K_CF64; *width = 16; *stride = (c->flags & SPEC_FLAG_REF_EDC_CF64_STRIDE8) ? 8 : 16; break;
+    default: *kind = K_CF32; *stride = *width = 8; break;  // EDC:94-96: everything else reads as float pairs
+    }
+}
+
+// decode (+ mix) `count` samples into device doubles d_re / d_im
+static spec_status burst_read(spec_ctx *c, const void *buffer, int on_device, uint64_t capacity, uint64_t start_sample,
+                              uint64_t count, spec_dtype dt, double freq_off, double *d_re, double *d_im) {
+    int kind; uint32_t stride, width;
+    edc_layout(c, dt, &kind, &stride, &width);
+    const uint64_t start_byte = start_sample * stride, span = (count - 1) * stride + width;
+    if (start_sample > capacity / stride || start_byte + span > capacity)
+        return fail(c, SPEC_ERANGE, "samples [%llu, %llu) leave the %llu-byte buffer", (unsigned long long)start_sample,
+                    (unsigned long long)(start_sample + count), (unsigned long long)capacity);
+    const uint8_t *d_raw;
+    if (on_device) {
+        d_raw = static_cast<const uint8_t *>(buffer) + start_byte;
+        if (reinterpret_cast<uintptr_t>(d_raw) % component_bytes(dt) != 0)
+            return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
+    } else {
+        spec_status st = grow(c, &c->stage_in, &c->stage_in_bytes, span);
+        if (st != SPEC_OK) return st;
+        HIP_TRY(c, hipMemcpyAsync(c->stage_in, static_cast<const uint8_t *>(buffer) + start_byte, span,
+                                  hipMemcpyHostToDevice, c->stream));
+        d_raw = static_cast<const uint8_t *>(c->stage_in);
+    }
+    hipError_t e = launch_extract_mix(d_raw, kind, is_be(dt), stride, count, freq_off, d_re, d_im, c->stream);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "reader launch: %s", hipGetErrorString(e));
+    return SPEC_OK;
+}
+
+spec_status spec_extract_iq(spec_ctx *c, const void *buffer, int buffer_on_device, uint64_t capacity,
+                            uint64_t start_sample, uint64_t count, spec_dtype dt, double *re, double *im,
+                            int out_on_device) {
+    if (!c) return SPEC_EINVAL;
+    if (!dtype_valid(dt)) return fail(c, SPEC_EINVAL, "bad datatype %d", (int)dt);
+    if (count == 0) return SPEC_OK;
+    if (!buffer || !re || !im) return fail(c, SPEC_EINVAL, "null buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double *d_re = re, *d_im = im;
+    if (!out_on_device) {
+        spec_status st = grow(c, &c->stage_out, &c->stage_out_bytes, 2 * count * sizeof(double));
+        if (st != SPEC_OK) return st;
+        d_re = static_cast<double *>(c->stage_out);
+        d_im = d_re + count;
+    }
+    spec_status st = burst_read(c, buffer, buffer_on_device, capacity, start_sample, count, dt, 0.0, d_re, d_im);
+    if (st != SPEC_OK) return st;
+    if (!out_on_device) {
+        HIP_TRY(c, hipMemcpyAsync(re, d_re, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(im, d_im, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!out_on_device || !buffer_on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPEC_OK;
+}
+
+spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_device, uint64_t capacity,
+                              uint64_t start_sample, uint64_t count, spec_dtype dt, double freq_off, uint32_t down,
+                              spec_downconv_mode mode, double *re_out, double *im_out, int out_on_device) {
+    if (!c) return SPEC_EINVAL;
+    if (!dtype_valid(dt)) return fail(c, SPEC_EINVAL, "bad datatype %d", (int)dt);
+    if (down == 0 || down > (1u << 20)) return fail(c, SPEC_EINVAL, "down = %u out of range", down);
+    if (mode != SPEC_DC_FAST && mode != SPEC_DC_LPF) return fail(c, SPEC_EINVAL, "bad mode %d", (int)mode);
+    if (!std::isfinite(freq_off)) return fail(c, SPEC_EINVAL, "freq_off must be finite");
+    const uint64_t n_out = count / down;
+    if (n_out == 0) return SPEC_OK;
+    if (!buffer || !re_out || !im_out) return fail(c, SPEC_EINVAL, "null buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // taps of the stated specification (include/specgpu.h), fp64 on the host
+    const uint32_t K = mode == SPEC_DC_FAST ? down : 8 * down + 1, centre = mode == SPEC_DC_FAST ? down - 1 : 4 * down;
+    std::vector<double> h(K);
+    if (mode == SPEC_DC_FAST) {
+        for (uint32_t k = 0; k < K; ++k) h[k] = 1.0 / (double)down;
+    } else {
+        double sum = 0.0;
+        for (uint32_t k = 0; k < K; ++k) {
+            const double x = ((double)k - 4.0 * down) / (double)down;
+            const double sinc = x == 0.0 ? 1.0 : std::sin(M_PI * x) / (M_PI * x);
+            h[k] = sinc * (0.54 - 0.46 * std::cos(2.0 * M_PI * (double)k / (double)(K - 1)));
+            sum += h[k];
+        }
+        for (uint32_t k = 0; k < K; ++k) h[k] /= sum;
+    }
+    // scratch: mixed samples (planar) + taps
+    const size_t need = (2 * count + K) * sizeof(double);
+    spec_status st = grow(c, &c->scratch, &c->scratch_bytes, need);
+    if (st != SPEC_OK) return st;
+    double *d_mr = static_cast<double *>(c->scratch), *d_mi = d_mr + count, *d_h = d_mi + count;
+    HIP_TRY(c, hipMemcpyAsync(d_h, h.data(), K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    st = burst_read(c, buffer, buffer_on_device, capacity, start_sample, count, dt, freq_off, d_mr, d_mi);
+    if (st != SPEC_OK) return st;
+    double *d_or = re_out, *d_oi = im_out;
+    if (!out_on_device) {
+        st = grow(c, &c->stage_out, &c->stage_out_bytes, 2 * n_out * sizeof(double));
+        if (st != SPEC_OK) return st;
+        d_or = static_cast<double *>(c->stage_out);
+        d_oi = d_or + n_out;
+    }
+    hipError_t e = launch_fir_decim(d_mr, d_mi, count, d_h, K, centre, down, d_or, d_oi, n_out, c->stream);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "filter launch: %s", hipGetErrorString(e));
+    if (!out_on_device) {
+        HIP_TRY(c, hipMemcpyAsync(re_out, d_or, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(im_out, d_oi, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `h` (pageable host memory) must outlive its copy
+    return SPEC_OK;
+}
+
+// shared body of the two traces: kind_trace 0 = magnitude (n outputs), 1 = frequency (n - 1 outputs)
+static spec_status run_trace(spec_ctx *c, int kind_trace, const double *re, const double *im, int in_on_device,
+                             uint64_t n, double alpha, double fs, double add, double *out, int out_on_device) {
+    if (!c) return SPEC_EINVAL;
+    const uint64_t n_out = kind_trace == 0 ? n : (n > 0 ? n - 1 : 0);
+    if (n_out == 0) return SPEC_OK;
+    if (!re || !im || !out) return fail(c, SPEC_EINVAL, "null buffer");
+    if (std::isnan(alpha)) return fail(c, SPEC_EINVAL, "alpha is NaN");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double *d_re = re, *d_im = im;
+    if (!in_on_device) {
+        spec_status st = grow(c, &c->stage_in, &c->stage_in_bytes, 2 * n * sizeof(double));
+        if (st != SPEC_OK) return st;
+        double *s = static_cast<double *>(c->stage_in);
+        HIP_TRY(c, hipMemcpyAsync(s, re, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(s + n, im, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        d_re = s;
+        d_im = s + n;
+    }
+    double *d_out = out;
+    if (!out_on_device) {
+        spec_status st = grow(c, &c->stage_out, &c->stage_out_bytes, n_out * sizeof(double));
+        if (st != SPEC_OK) return st;
+        d_out = static_cast<double *>(c->stage_out);
+    }
+    spec_status st = grow(c, &c->scratch2, &c->scratch2_bytes, trace_scratch_bytes(n_out));
+    if (st != SPEC_OK) return st;
+    hipError_t e = launch_trace(kind_trace, d_re, d_im, n_out, alpha, fs, add, c->scratch2, d_out, c->stream);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "trace launch: %s", hipGetErrorString(e));
+    if (!out_on_device) HIP_TRY(c, hipMemcpyAsync(out, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!out_on_device || !in_on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPEC_OK;
+}
+
+spec_status spec_magnitude_trace(spec_ctx *c, const double *re, const double *im, int in_on_device, uint64_t n,
+                                 double alpha, double *db_out, int out_on_device) {
+    return run_trace(c, 0, re, im, in_on_device, n, alpha, 0.0, 0.0, db_out, out_on_device);
+}
+
+spec_status spec_inst_freq_trace(spec_ctx *c, const double *re, const double *im, int in_on_device, uint64_t n,
+                                 double alpha, double fs, double center_freq, double *hz_out, int out_on_device) {
+    return run_trace(c, 1, re, im, in_on_device, n, alpha, fs, center_freq, hz_out, out_on_device);
+}
+
 spec_status spec_synth_iq(spec_ctx *c, void *dev_out, spec_dtype dt, uint64_t seed, uint64_t first_sample,
                           uint64_t n_samples) {
     if (!c) return SPEC_EINVAL;

@@ -69,4 +69,14 @@ hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint3
 hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t first_sample,
                         uint64_t n_samples, hipStream_t s);
 
+// burst chain (spec_burst.hip): reader + mixer, FIR + decimate, EMA traces (fp64)
+hipError_t launch_extract_mix(const uint8_t *raw, int kind, int be, uint32_t stride, uint64_t count, double freq_off,
+                              double *re, double *im, hipStream_t s);
+hipError_t launch_fir_decim(const double *mr, const double *mi, uint64_t n, const double *h, uint32_t K, uint32_t c,
+                            uint32_t down, double *ore, double *oim, uint64_t n_out, hipStream_t s);
+size_t trace_scratch_bytes(uint64_t n_out);
+// kind_trace 0: magnitude (n_out = n), 1: instantaneous frequency (n_out = n - 1)
+hipError_t launch_trace(int kind_trace, const double *re, const double *im, uint64_t n_out, double alpha, double fs,
+                        double add, void *scratch, double *out, hipStream_t s);
+
 }  // namespace specgpu

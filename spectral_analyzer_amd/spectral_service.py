@@ -57,7 +57,8 @@ def _host_bytes(buffer) -> np.ndarray:
 class SpectralService:
     """GPU-backed drop-in for the reference ``SpectralService`` singleton."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None, ref_cf64_zero: bool = False):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, ref_cf64_zero: bool = False,
+                 ref_edc_cf64_stride8: bool = False):
         """``stream`` is a hipStream_t handle (e.g. ``torch.cuda.Stream().cuda_stream``);
         None means the device's default stream, so device-resident results are
         ordered with PyTorch work on its default stream.  Device-pointer calls
@@ -65,6 +66,8 @@ class SpectralService:
         self._lib = L.load()
         self._ctx = C.c_void_p()
         flags = L.FLAG_REF_CF64_ZERO if ref_cf64_zero else 0
+        if ref_edc_cf64_stride8:
+            flags |= L.FLAG_REF_EDC_CF64_STRIDE8
         if not stream:
             flags |= L.FLAG_NULL_STREAM
         st = self._lib.spec_create(int(device), C.c_void_p(stream) if stream else None, flags,
@@ -252,6 +255,45 @@ class SpectralService:
             self._ctx, d[0].ctypes.data, d[1].ctypes.data, d.shape[1], int(nfft) & 0xFFFFFFFF, hop, window,
             scaling, float(fs), int(db), freq.ctypes.data, psd.ctypes.data))
         return np.stack([freq, psd.astype(np.float64)])
+
+    # -- Analysis dialog traces (ADC:219-284) --------------------------------
+    def _planar(self, data):
+        """``double[2][N]`` (row 0 = I, row 1 = Q) as two device pointers or two host arrays."""
+        if _is_torch(data):
+            import torch
+            if data.dtype != torch.float64 or data.dim() != 2 or data.shape[0] != 2 or not data.is_contiguous():
+                raise ValueError("expected a contiguous float64 tensor of shape [2, N]")
+            n = int(data.shape[1])
+            return data, data.data_ptr(), data.data_ptr() + 8 * n, n, 1
+        a = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
+        if a.ndim != 2 or a.shape[0] != 2:
+            raise ValueError("expected double[2][N]")
+        return a, a[0].ctypes.data, a[1].ctypes.data, int(a.shape[1]), 0
+
+    def _trace_out(self, like, n: int, on_device: int):
+        if on_device:
+            import torch
+            out = torch.empty(n, dtype=torch.float64, device=like.device)
+            return out, out.data_ptr()
+        out = np.empty(n, dtype=np.float64)
+        return out, out.ctypes.data
+
+    def magnitude_trace(self, data, alpha: float):
+        """``updateMagnitudeChart`` (ADC:219-246): ``20 log10`` of the EMA of ``hypot(I, Q)``,
+        one value per sample (non-finite values are the caller's to drop, ADC:239-242)."""
+        keep, pre, pim, n, dev = self._planar(data)
+        out, pout = self._trace_out(keep, n, dev)
+        self._check(self._lib.spec_magnitude_trace(self._ctx, pre, pim, dev, n, float(alpha), pout, dev))
+        return out
+
+    def inst_freq_trace(self, data, alpha: float, fs: float, center_freq: float = 0.0):
+        """``updateFrequencyChart`` (ADC:256-284): EMA of the wrapped phase step in Hz plus the
+        centre frequency, ``N - 1`` values (samples 1 .. N-1)."""
+        keep, pre, pim, n, dev = self._planar(data)
+        out, pout = self._trace_out(keep, max(n - 1, 0), dev)
+        self._check(self._lib.spec_inst_freq_trace(self._ctx, pre, pim, dev, n, float(alpha), float(fs),
+                                                   float(center_freq), pout, dev))
+        return out
 
     # -- synthetic recording (bench / tests) --------------------------------
     def synth_iq(self, datatype: str, seed: int, first_sample: int, n_samples: int, out=None):

@@ -155,7 +155,7 @@ def test_welch_matches_scipy(oracle, scaling, window):
 def test_golden_fixtures(oracle):
     """tests/golden/*.npz were written by tests/golden/make_golden.py from the C oracle after
     the numpy cross-check; they freeze the expected lines so a later oracle edit cannot drift."""
-    files = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    files = sorted(f for f in os.listdir(GOLDEN) if f.startswith("wf_") and f.endswith(".npz"))
     assert files, "no golden fixtures committed"
     for f in files:
         g = np.load(os.path.join(GOLDEN, f))
