@@ -52,6 +52,31 @@ public:
         return {f, std::vector<double>(p.begin(), p.end())};
     }
 
+    // ExtractDownConvertService.extractAndDownConvert (ExtractDownConvertService.java:54-117): {I, Q} of
+    // count / down samples; freqOff in cycles per input sample, `fast` as in the reference
+    std::vector<std::vector<double>> extractAndDownConvert(const void *buffer, uint64_t capacity, uint64_t startSample,
+                                                           uint64_t count, const std::string &datatype, double freqOff,
+                                                           uint32_t down, bool fast) const {
+        if (down == 0) throw std::invalid_argument("down must be >= 1");
+        std::vector<double> re(count / down), im(count / down);
+        check(spec_down_convert(ctx_, buffer, 0, capacity, startSample, count, spec_dtype_from_sigmf(datatype.c_str()),
+                                freqOff, down, fast ? SPEC_DC_FAST : SPEC_DC_LPF, re.data(), im.data(), 0), ctx_);
+        return {re, im};
+    }
+
+    // AnalysisDialogController.updateMagnitudeChart / updateFrequencyChart (ADC:219-284)
+    std::vector<double> magnitudeTrace(const double *re, const double *im, uint64_t n, double alpha) const {
+        std::vector<double> out(n);
+        check(spec_magnitude_trace(ctx_, re, im, 0, n, alpha, out.data(), 0), ctx_);
+        return out;
+    }
+    std::vector<double> instFreqTrace(const double *re, const double *im, uint64_t n, double alpha, double fs,
+                                      double centerFreq) const {
+        std::vector<double> out(n ? n - 1 : 0);
+        check(spec_inst_freq_trace(ctx_, re, im, 0, n, alpha, fs, centerFreq, out.data(), 0), ctx_);
+        return out;
+    }
+
     spec_ctx *handle() const { return ctx_; }
 
 private:

@@ -110,6 +110,27 @@ public class SpectralService implements AutoCloseable {
         return new double[][] {freq, wide};
     }
 
+    /**
+     * The loop of {@code AnalysisDialogController.updateMagnitudeChart}: {@code 20 log10} of the
+     * exponential moving average (weight {@code alpha}) of {@code hypot(data[0][i], data[1][i])},
+     * one value per sample; the caller skips non-finite values as the dialog does.
+     */
+    public double[] magnitudeTrace(double[][] data, double alpha) {
+        double[] out = new double[data[0].length];
+        nativeTrace(handle, 0, data[0], data[1], alpha, 0.0, 0.0, out);
+        return out;
+    }
+
+    /**
+     * The loop of {@code AnalysisDialogController.updateFrequencyChart}: smoothed instantaneous
+     * frequency in Hz plus {@code centerFreq}, for samples 1 .. N-1.
+     */
+    public double[] instFreqTrace(double[][] data, double alpha, double sampleRate, double centerFreq) {
+        double[] out = new double[Math.max(data[0].length - 1, 0)];
+        nativeTrace(handle, 1, data[0], data[1], alpha, sampleRate, centerFreq, out);
+        return out;
+    }
+
     @Override
     public void close() {
         nativeDestroy(handle);
@@ -131,5 +152,7 @@ public class SpectralService implements AutoCloseable {
     private static native void nativeWelchPlanar(long handle, double[] re, double[] im, int nfft, int hop,
                                                  int window, int scaling, double sampleRate, boolean decibel,
                                                  double[] freq, float[] psd);
+    private static native void nativeTrace(long handle, int which, double[] re, double[] im, double alpha,
+                                           double sampleRate, double centerFreq, double[] out);
     private static native int nativeDtype(String datatype);
 }

@@ -2,8 +2,8 @@
  * specgpu_jni.c -- thin JNI shim between the Java host and the C ABI of
  * include/specgpu.h.  One native method per C entry point; no arithmetic here.
  *
- * Java class bound: net.kcundercover.spectral_analyzer.services.SpectralService
- * (the '_' of "spectral_analyzer" is mangled as "_1").  The MappedByteBuffer the
+ * Java classes bound: net.kcundercover.spectral_analyzer.services.SpectralService and
+ * ...services.ExtractDownConvertService (the '_' of "spectral_analyzer" is mangled as "_1").  The MappedByteBuffer the
  * reference hands to computeMagnitudes (SpectralService.java:33,
  * SigMfHelper.java:84) is a direct buffer, so GetDirectBufferAddress gives the
  * mapped bytes without a copy.
@@ -153,4 +153,68 @@ JNIEXPORT jint JNICALL JNI_FN(nativeDtype)(JNIEnv *env, jclass k, jstring dataty
     jint v = (jint)spec_dtype_from_sigmf(dt);
     (*env)->ReleaseStringUTFChars(env, datatype, dt);
     return v;
+}
+
+/* AnalysisDialogController.updateMagnitudeChart / updateFrequencyChart loops (ADC:219-284):
+ * which == 0: out[n] = 20 log10(EMA(hypot)); which == 1: out[n-1] = EMA(phase step in Hz) + centerFreq */
+JNIEXPORT void JNICALL JNI_FN(nativeTrace)(JNIEnv *env, jclass k, jlong h, jint which, jdoubleArray re,
+                                            jdoubleArray im, jdouble alpha, jdouble fs, jdouble centerFreq,
+                                            jdoubleArray out) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    jsize n = (*env)->GetArrayLength(env, re);
+    if ((*env)->GetArrayLength(env, im) != n || (*env)->GetArrayLength(env, out) < (which ? n - 1 : n)) {
+        throw_status(env, ctx, SPEC_EINVAL);
+        return;
+    }
+    jdouble *r = (*env)->GetDoubleArrayElements(env, re, NULL);
+    jdouble *i = (*env)->GetDoubleArrayElements(env, im, NULL);
+    jdouble *o = (*env)->GetDoubleArrayElements(env, out, NULL);
+    spec_status st = which ? spec_inst_freq_trace(ctx, r, i, 0, (uint64_t)n, alpha, fs, centerFreq, o, 0)
+                           : spec_magnitude_trace(ctx, r, i, 0, (uint64_t)n, alpha, o, 0);
+    (*env)->ReleaseDoubleArrayElements(env, out, o, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, im, i, JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, re, r, JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
+/* ---- net.kcundercover.spectral_analyzer.services.ExtractDownConvertService ------------------- */
+#define EDC_FN(name) Java_net_kcundercover_spectral_1analyzer_services_ExtractDownConvertService_##name
+
+JNIEXPORT jlong JNICALL EDC_FN(nativeCreate)(JNIEnv *env, jclass k, jint device, jint flags) {
+    return JNI_FN(nativeCreate)(env, k, device, flags);
+}
+
+JNIEXPORT void JNICALL EDC_FN(nativeDestroy)(JNIEnv *env, jclass k, jlong h) { JNI_FN(nativeDestroy)(env, k, h); }
+
+/* double[][] extractAndDownConvert(MappedByteBuffer, long startSample, int count, String datatype,
+ *                                  double freqOff, int down, boolean fast) -- EDC:54-117;
+ * re / im receive count / down samples each */
+JNIEXPORT void JNICALL EDC_FN(nativeExtractAndDownConvert)(JNIEnv *env, jclass k, jlong h, jobject buffer,
+                                                            jlong startSample, jint count, jstring datatype,
+                                                            jboolean bigEndian, jdouble freqOff, jint down,
+                                                            jboolean fast, jdoubleArray re, jdoubleArray im) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    void *base = (*env)->GetDirectBufferAddress(env, buffer);
+    jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
+    if (!base || cap < 0 || startSample < 0 || count < 0 || down <= 0 ||
+        (*env)->GetArrayLength(env, re) < count / down || (*env)->GetArrayLength(env, im) < count / down) {
+        throw_status(env, ctx, SPEC_EINVAL);
+        return;
+    }
+    const char *s = (*env)->GetStringUTFChars(env, datatype, NULL);
+    spec_dtype dt = spec_dtype_from_sigmf(s);
+    (*env)->ReleaseStringUTFChars(env, datatype, s);
+    /* byte order is the buffer's (SigMfHelper.java:87-91), not the string's */
+    if (dt == SPEC_DT_CI16_LE || dt == SPEC_DT_CI16_BE) dt = bigEndian ? SPEC_DT_CI16_BE : SPEC_DT_CI16_LE;
+    else if (dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE) dt = bigEndian ? SPEC_DT_CF64_BE : SPEC_DT_CF64_LE;
+    else if (dt != SPEC_DT_CU8 && dt != SPEC_DT_CI8) dt = bigEndian ? SPEC_DT_CF32_BE : SPEC_DT_CF32_LE; /* EDC:94-96 */
+    jdouble *r = (*env)->GetDoubleArrayElements(env, re, NULL);
+    jdouble *i = (*env)->GetDoubleArrayElements(env, im, NULL);
+    spec_status st = spec_down_convert(ctx, base, 0, (uint64_t)cap, (uint64_t)startSample, (uint64_t)count, dt,
+                                       freqOff, (uint32_t)down, fast ? SPEC_DC_FAST : SPEC_DC_LPF, r, i, 0);
+    (*env)->ReleaseDoubleArrayElements(env, im, i, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, re, r, st == SPEC_OK ? 0 : JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
 }

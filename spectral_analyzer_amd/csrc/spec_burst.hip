@@ -22,33 +22,59 @@ __device__ __forceinline__ uint64_t ld_u64(const uint8_t *p, bool be) {
     return be ? __builtin_bswap64(u) : u;
 }
 
+// sample i of the burst, decoded (EDC:79-96) and shifted by freq_off cycles per sample
+__device__ __forceinline__ cx<double> read_mixed(const uint8_t *__restrict__ raw, int kind, int be, uint32_t stride,
+                                                 uint64_t i, double freq_off) {
+    const uint8_t *p = raw + i * stride;
+    double x, y;
+    if (kind == K_CF64) {  // two 8-byte loads: the reference's 8-byte stride (EDC:60-67) is not 16-byte aligned
+        x = __longlong_as_double((long long)ld_u64(p, be));
+        y = __longlong_as_double((long long)ld_u64(p + 8, be));
+    } else {
+        const cx<double> z = decode_sample<double>(p, kind, be);
+        x = z.x;
+        y = z.y;
+    }
+    if (freq_off != 0.0) {  // x exp(-2 pi i frac(freq_off n))
+        // the phase is the ROUNDED product minus its floor (the serial definition); the empty asm keeps
+        // the backend (-ffp-contract=fast) from fusing the multiply into the subtraction
+        double t = freq_off * (double)i;
+        asm volatile("" : "+v"(t));
+        t -= floor(t);
+        const double a = 2.0 * kPi * t, cs = cos(a), sn = sin(a);
+        const double xr = x * cs + y * sn, xi = y * cs - x * sn;
+        x = xr;
+        y = xi;
+    }
+    return {x, y};
+}
+
 __global__ __launch_bounds__(256) void extract_mix_kernel(const uint8_t *__restrict__ raw, int kind, int be,
                                                           uint32_t stride, uint64_t count, double freq_off,
                                                           double *__restrict__ re, double *__restrict__ im) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
-        const uint8_t *p = raw + i * stride;
-        double x, y;
-        if (kind == K_CF64) {  // two 8-byte loads: the reference's 8-byte stride (EDC:60-67) is not 16-byte aligned
-            x = __longlong_as_double((long long)ld_u64(p, be));
-            y = __longlong_as_double((long long)ld_u64(p + 8, be));
-        } else {
-            const cx<double> z = decode_sample<double>(p, kind, be);
-            x = z.x;
-            y = z.y;
+        const cx<double> z = read_mixed(raw, kind, be, stride, i, freq_off);
+        re[i] = z.x;
+        im[i] = z.y;
+    }
+}
+
+// "fast" mode in one pass (every sample is used by exactly one output): reader, mixer and the
+// boxcar of `down` taps, summed in the tap order of the definition (k ascending = index descending)
+__global__ __launch_bounds__(256) void boxcar_decim_kernel(const uint8_t *__restrict__ raw, int kind, int be,
+                                                           uint32_t stride, double freq_off, uint32_t down,
+                                                           double *__restrict__ ore, double *__restrict__ oim,
+                                                           uint64_t n_out) {
+    const double h = 1.0 / (double)down;
+    for (uint64_t m = (uint64_t)blockIdx.x * 256 + threadIdx.x; m < n_out; m += (uint64_t)gridDim.x * 256) {
+        double ar = 0.0, ai = 0.0;
+        for (uint32_t k = 0; k < down; ++k) {
+            const cx<double> z = read_mixed(raw, kind, be, stride, m * down + (down - 1 - k), freq_off);
+            ar += h * z.x;
+            ai += h * z.y;
         }
-        if (freq_off != 0.0) {  // x exp(-2 pi i frac(freq_off n))
-            // the phase is the ROUNDED product minus its floor (the serial definition); the empty asm keeps
-            // the backend (-ffp-contract=fast) from fusing the multiply into the subtraction
-            double t = freq_off * (double)i;
-            asm volatile("" : "+v"(t));
-            t -= floor(t);
-            const double a = 2.0 * kPi * t, cs = cos(a), sn = sin(a);
-            const double xr = x * cs + y * sn, xi = y * cs - x * sn;
-            x = xr;
-            y = xi;
-        }
-        re[i] = x;
-        im[i] = y;
+        ore[m] = ar;
+        oim[m] = ai;
     }
 }
 
@@ -75,17 +101,24 @@ __global__ __launch_bounds__(256) void fir_decim_kernel(const double *__restrict
 struct Aff { double a, b; };  // v -> a v + b
 __device__ __forceinline__ Aff then(Aff first, Aff second) { return {first.a * second.a, second.a * first.b + second.b}; }
 
-// element j of the trace's input sequence
+// inputs j0 .. j0 + TR_ITEMS - 1 of the trace's sequence (zeros past n_out)
 template <int KIND_TRACE>
-__device__ __forceinline__ double trace_input(const double *__restrict__ re, const double *__restrict__ im,
-                                              uint64_t j, double fs) {
+__device__ __forceinline__ void trace_inputs(const double *__restrict__ re, const double *__restrict__ im, uint64_t j0,
+                                             uint64_t n_out, double fs, double (&x)[TR_ITEMS]) {
     if constexpr (KIND_TRACE == 0) {
-        return hypot(re[j], im[j]);  // ADC:230
-    } else {                         // ADC:265-276, output j is sample i = j + 1
-        double d = atan2(im[j + 1], re[j + 1]) - atan2(im[j], re[j]);
-        if (d > kPi) d -= 2 * kPi;
-        else if (d < -kPi) d += 2 * kPi;
-        return (d / (2 * kPi)) * fs;
+#pragma unroll
+        for (int k = 0; k < TR_ITEMS; ++k) x[k] = j0 + k < n_out ? hypot(re[j0 + k], im[j0 + k]) : 0.0;  // ADC:230
+    } else {  // ADC:265-276, output j is sample i = j + 1: one atan2 per sample, shared by two outputs
+        double ph[TR_ITEMS + 1];
+#pragma unroll
+        for (int k = 0; k <= TR_ITEMS; ++k) ph[k] = j0 + k <= n_out ? atan2(im[j0 + k], re[j0 + k]) : 0.0;
+#pragma unroll
+        for (int k = 0; k < TR_ITEMS; ++k) {
+            double d = ph[k + 1] - ph[k];
+            if (d > kPi) d -= 2 * kPi;
+            else if (d < -kPi) d += 2 * kPi;
+            x[k] = j0 + k < n_out ? (d / (2 * kPi)) * fs : 0.0;
+        }
     }
 }
 
@@ -115,20 +148,24 @@ template <int KIND_TRACE, bool FINAL>
 __global__ __launch_bounds__(TR_THREADS) void trace_kernel(const double *__restrict__ re, const double *__restrict__ im,
                                                            uint64_t n_out, double alpha, double fs, double add,
                                                            Aff *__restrict__ tile_aff, const double *__restrict__ carry,
-                                                           double *__restrict__ out) {
+                                                           double *out) {
     __shared__ Aff lds[TR_THREADS];
     const uint64_t j0 = (uint64_t)blockIdx.x * TR_TILE + (uint64_t)threadIdx.x * TR_ITEMS;
     double x[TR_ITEMS];
+    if constexpr (!FINAL) {  // first pass: compute the inputs and park them in `out` for the last pass
+        trace_inputs<KIND_TRACE>(re, im, j0, n_out, fs, x);
+#pragma unroll
+        for (int k = 0; k < TR_ITEMS; ++k)
+            if (j0 + k < n_out) out[j0 + k] = x[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < TR_ITEMS; ++k) x[k] = j0 + k < n_out ? out[j0 + k] : 0.0;
+    }
     Aff agg{1.0, 0.0};
 #pragma unroll
     for (int k = 0; k < TR_ITEMS; ++k) {
         const uint64_t j = j0 + k;
-        if (j < n_out) {
-            x[k] = trace_input<KIND_TRACE>(re, im, j, fs);
-            agg = then(agg, j == 0 ? Aff{0.0, x[k]} : Aff{1 - alpha, alpha * x[k]});  // ADC:233-237 / 277-281
-        } else {
-            x[k] = 0.0;
-        }
+        if (j < n_out) agg = then(agg, j == 0 ? Aff{0.0, x[k]} : Aff{1 - alpha, alpha * x[k]});  // ADC:233-237 / 277-281
     }
     Aff total;
     const Aff excl = wg_scan(agg, lds, &total);
@@ -175,6 +212,15 @@ hipError_t launch_extract_mix(const uint8_t *raw, int kind, int be, uint32_t str
     return hipGetLastError();
 }
 
+hipError_t launch_boxcar_decim(const uint8_t *raw, int kind, int be, uint32_t stride, double freq_off, uint32_t down,
+                               double *ore, double *oim, uint64_t n_out, hipStream_t s) {
+    if (n_out == 0) return hipSuccess;
+    const uint64_t wgs = (n_out + 255) / 256;
+    hipLaunchKernelGGL(boxcar_decim_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(256), 0, s, raw, kind, be,
+                       stride, freq_off, down, ore, oim, n_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_fir_decim(const double *mr, const double *mi, uint64_t n, const double *h, uint32_t K, uint32_t c,
                             uint32_t down, double *ore, double *oim, uint64_t n_out, hipStream_t s) {
     if (n_out == 0) return hipSuccess;
@@ -198,13 +244,13 @@ hipError_t launch_trace(int kind_trace, const double *re, const double *im, uint
     double *carry = reinterpret_cast<double *>(tile_aff + tiles);
     if (kind_trace == 0) {
         hipLaunchKernelGGL((trace_kernel<0, false>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
-                           add, tile_aff, nullptr, nullptr);
+                           add, tile_aff, nullptr, out);
         hipLaunchKernelGGL(trace_carry_kernel, dim3(1), dim3(TR_THREADS), 0, s, tile_aff, (uint32_t)tiles, carry);
         hipLaunchKernelGGL((trace_kernel<0, true>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
                            add, tile_aff, carry, out);
     } else {
         hipLaunchKernelGGL((trace_kernel<1, false>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
-                           add, tile_aff, nullptr, nullptr);
+                           add, tile_aff, nullptr, out);
         hipLaunchKernelGGL(trace_carry_kernel, dim3(1), dim3(TR_THREADS), 0, s, tile_aff, (uint32_t)tiles, carry);
         hipLaunchKernelGGL((trace_kernel<1, true>), dim3((unsigned)tiles), dim3(TR_THREADS), 0, s, re, im, n_out, alpha, fs,
                            add, tile_aff, carry, out);

@@ -710,27 +710,35 @@ static void edc_layout(const spec_ctx *c, spec_dtype dt, int *kind, uint32_t *st
     }
 }
 
-// decode (+ mix) `count` samples into device doubles d_re / d_im
-static spec_status burst_read(spec_ctx *c, const void *buffer, int on_device, uint64_t capacity, uint64_t start_sample,
-                              uint64_t count, spec_dtype dt, double freq_off, double *d_re, double *d_im) {
-    int kind; uint32_t stride, width;
-    edc_layout(c, dt, &kind, &stride, &width);
-    const uint64_t start_byte = start_sample * stride, span = (count - 1) * stride + width;
-    if (start_sample > capacity / stride || start_byte + span > capacity)
+// range-check the burst and make its raw bytes device-resident: *d_raw points at sample start_sample
+static spec_status burst_locate(spec_ctx *c, const void *buffer, int on_device, uint64_t capacity, uint64_t start_sample,
+                                uint64_t count, spec_dtype dt, const uint8_t **d_raw, int *kind, uint32_t *stride) {
+    uint32_t width;
+    edc_layout(c, dt, kind, stride, &width);
+    const uint64_t start_byte = start_sample * *stride, span = (count - 1) * *stride + width;
+    if (start_sample > capacity / *stride || start_byte + span > capacity)
         return fail(c, SPEC_ERANGE, "samples [%llu, %llu) leave the %llu-byte buffer", (unsigned long long)start_sample,
                     (unsigned long long)(start_sample + count), (unsigned long long)capacity);
-    const uint8_t *d_raw;
     if (on_device) {
-        d_raw = static_cast<const uint8_t *>(buffer) + start_byte;
-        if (reinterpret_cast<uintptr_t>(d_raw) % component_bytes(dt) != 0)
+        *d_raw = static_cast<const uint8_t *>(buffer) + start_byte;
+        if (reinterpret_cast<uintptr_t>(*d_raw) % component_bytes(dt) != 0)
             return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
     } else {
         spec_status st = grow(c, &c->stage_in, &c->stage_in_bytes, span);
         if (st != SPEC_OK) return st;
         HIP_TRY(c, hipMemcpyAsync(c->stage_in, static_cast<const uint8_t *>(buffer) + start_byte, span,
                                   hipMemcpyHostToDevice, c->stream));
-        d_raw = static_cast<const uint8_t *>(c->stage_in);
+        *d_raw = static_cast<const uint8_t *>(c->stage_in);
     }
+    return SPEC_OK;
+}
+
+// decode (+ mix) `count` samples into device doubles d_re / d_im
+static spec_status burst_read(spec_ctx *c, const void *buffer, int on_device, uint64_t capacity, uint64_t start_sample,
+                              uint64_t count, spec_dtype dt, double freq_off, double *d_re, double *d_im) {
+    const uint8_t *d_raw; int kind; uint32_t stride;
+    spec_status st = burst_locate(c, buffer, on_device, capacity, start_sample, count, dt, &d_raw, &kind, &stride);
+    if (st != SPEC_OK) return st;
     hipError_t e = launch_extract_mix(d_raw, kind, is_be(dt), stride, count, freq_off, d_re, d_im, c->stream);
     if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "reader launch: %s", hipGetErrorString(e));
     return SPEC_OK;
@@ -773,12 +781,23 @@ spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_dev
     if (n_out == 0) return SPEC_OK;
     if (!buffer || !re_out || !im_out) return fail(c, SPEC_EINVAL, "null buffer");
     HIP_TRY(c, hipSetDevice(c->device));
-    // taps of the stated specification (include/specgpu.h), fp64 on the host
-    const uint32_t K = mode == SPEC_DC_FAST ? down : 8 * down + 1, centre = mode == SPEC_DC_FAST ? down - 1 : 4 * down;
-    std::vector<double> h(K);
-    if (mode == SPEC_DC_FAST) {
-        for (uint32_t k = 0; k < K; ++k) h[k] = 1.0 / (double)down;
+    double *d_or = re_out, *d_oi = im_out;
+    if (!out_on_device) {
+        spec_status st = grow(c, &c->stage_out, &c->stage_out_bytes, 2 * n_out * sizeof(double));
+        if (st != SPEC_OK) return st;
+        d_or = static_cast<double *>(c->stage_out);
+        d_oi = d_or + n_out;
+    }
+    if (mode == SPEC_DC_FAST) {  // every sample feeds exactly one output: reader, mixer and boxcar in one pass
+        const uint8_t *d_raw; int kind; uint32_t stride;
+        spec_status st = burst_locate(c, buffer, buffer_on_device, capacity, start_sample, count, dt, &d_raw, &kind, &stride);
+        if (st != SPEC_OK) return st;
+        hipError_t e = launch_boxcar_decim(d_raw, kind, is_be(dt), stride, freq_off, down, d_or, d_oi, n_out, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "filter launch: %s", hipGetErrorString(e));
     } else {
+        // taps of the stated specification (include/specgpu.h), fp64 on the host
+        const uint32_t K = 8 * down + 1, centre = 4 * down;
+        std::vector<double> h(K);
         double sum = 0.0;
         for (uint32_t k = 0; k < K; ++k) {
             const double x = ((double)k - 4.0 * down) / (double)down;
@@ -787,29 +806,24 @@ spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_dev
             sum += h[k];
         }
         for (uint32_t k = 0; k < K; ++k) h[k] /= sum;
-    }
-    // scratch: mixed samples (planar) + taps
-    const size_t need = (2 * count + K) * sizeof(double);
-    spec_status st = grow(c, &c->scratch, &c->scratch_bytes, need);
-    if (st != SPEC_OK) return st;
-    double *d_mr = static_cast<double *>(c->scratch), *d_mi = d_mr + count, *d_h = d_mi + count;
-    HIP_TRY(c, hipMemcpyAsync(d_h, h.data(), K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    st = burst_read(c, buffer, buffer_on_device, capacity, start_sample, count, dt, freq_off, d_mr, d_mi);
-    if (st != SPEC_OK) return st;
-    double *d_or = re_out, *d_oi = im_out;
-    if (!out_on_device) {
-        st = grow(c, &c->stage_out, &c->stage_out_bytes, 2 * n_out * sizeof(double));
+        // scratch: mixed samples (planar) + taps
+        spec_status st = grow(c, &c->scratch, &c->scratch_bytes, (2 * count + K) * sizeof(double));
         if (st != SPEC_OK) return st;
-        d_or = static_cast<double *>(c->stage_out);
-        d_oi = d_or + n_out;
+        double *d_mr = static_cast<double *>(c->scratch), *d_mi = d_mr + count, *d_h = d_mi + count;
+        HIP_TRY(c, hipMemcpyAsync(d_h, h.data(), K * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        st = burst_read(c, buffer, buffer_on_device, capacity, start_sample, count, dt, freq_off, d_mr, d_mi);
+        if (st == SPEC_OK) {
+            hipError_t e = launch_fir_decim(d_mr, d_mi, count, d_h, K, centre, down, d_or, d_oi, n_out, c->stream);
+            if (e != hipSuccess) st = fail(c, SPEC_EDEVICE, "filter launch: %s", hipGetErrorString(e));
+        }
+        (void)hipStreamSynchronize(c->stream);  // `h` (pageable host memory) must outlive its copy
+        if (st != SPEC_OK) return st;
     }
-    hipError_t e = launch_fir_decim(d_mr, d_mi, count, d_h, K, centre, down, d_or, d_oi, n_out, c->stream);
-    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "filter launch: %s", hipGetErrorString(e));
     if (!out_on_device) {
         HIP_TRY(c, hipMemcpyAsync(re_out, d_or, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(im_out, d_oi, n_out * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // `h` (pageable host memory) must outlive its copy
+    if (!out_on_device || !buffer_on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPEC_OK;
 }
 

@@ -72,6 +72,8 @@ hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t fir
 // burst chain (spec_burst.hip): reader + mixer, FIR + decimate, EMA traces (fp64)
 hipError_t launch_extract_mix(const uint8_t *raw, int kind, int be, uint32_t stride, uint64_t count, double freq_off,
                               double *re, double *im, hipStream_t s);
+hipError_t launch_boxcar_decim(const uint8_t *raw, int kind, int be, uint32_t stride, double freq_off, uint32_t down,
+                               double *ore, double *oim, uint64_t n_out, hipStream_t s);
 hipError_t launch_fir_decim(const double *mr, const double *mi, uint64_t n, const double *h, uint32_t K, uint32_t c,
                             uint32_t down, double *ore, double *oim, uint64_t n_out, hipStream_t s);
 size_t trace_scratch_bytes(uint64_t n_out);

@@ -104,3 +104,17 @@ def test_header_is_plain_c_and_cpp(tmp_path):
     rc = subprocess.call([str(tmp_path / "example")])
     import torch
     assert rc == (0 if torch.cuda.is_available() else 2)
+
+
+def test_jni_shim_covers_every_java_native_method():
+    """No JDK here, so at least keep the two sides of the JNI boundary in step: every `native`
+    method of the replacement Java classes has its mangled function in the shim, and vice versa."""
+    import re
+    shim = open(os.path.join(ROOT, "integration", "jni", "specgpu_jni.c")).read()
+    jdir = os.path.join(ROOT, "integration", "java", "net", "kcundercover", "spectral_analyzer", "services")
+    for cls, macro in (("SpectralService", "JNI_FN"), ("ExtractDownConvertService", "EDC_FN")):
+        java = open(os.path.join(jdir, cls + ".java")).read()
+        declared = set(re.findall(r"private static native [\w\[\]]+ (native\w+)\(", java))
+        defined = set(re.findall(r"JNICALL %s\((native\w+)\)" % macro, shim))
+        assert declared and declared == defined, (cls, declared ^ defined)
+    assert "Java_net_kcundercover_spectral_1analyzer_services_ExtractDownConvertService_" in shim
