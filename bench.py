@@ -75,11 +75,20 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
+    # SPEC_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a ONE-GPU box -- every rank on device 0,
+    # gloo instead of RCCL (which refuses two ranks on one device).  Never used by the driver.
+    rehearse = os.environ.get("SPEC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if rehearse else None  # device of the two scalar reductions
 
     import spectral_analyzer_amd as sa
     from spectral_analyzer_amd import _lib as L
@@ -128,10 +137,10 @@ def main() -> None:
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=iq.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev or iq.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([kern_ms], dtype=torch.float64, device=iq.device)
+        k = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev or iq.device)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kern_ms = float(k.item())
 
