@@ -4,12 +4,16 @@
 #include "../../include/specgpu.h"
 
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "spec_fft.h"
@@ -33,8 +37,12 @@ struct spec_ctx {
     void *scratch = nullptr;   size_t scratch_bytes = 0;   // large-N transposes, Welch slabs
     void *scratch2 = nullptr;  size_t scratch2_bytes = 0;  // fallback Welch: power lines + accumulator
     // tuning / testing knobs (spec_set_option)
-    int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024;
+    int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
     int n_cu = 256;
+    // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
+    // them against the compute stream, created on first use
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
 };
 
 static thread_local std::string g_create_err;
@@ -168,6 +176,12 @@ void spec_destroy(spec_ctx *c) {
     (void)hipFree(c->stage_out);
     (void)hipFree(c->scratch);
     (void)hipFree(c->scratch2);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -187,6 +201,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "force_generic")) c->opt_force_generic = value;
     else if (!strcmp(key, "lines_per_wg")) c->opt_lines_per_wg = value < 0 ? 0 : value;
     else if (!strcmp(key, "large_chunk_mb")) c->opt_large_chunk_mb = value < 1 ? 1 : value;
+    else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
     return SPEC_OK;
 }
@@ -409,42 +424,151 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
         return SPEC_OK;
     }
 
-    // staged path: walk the valid lines in chunks that fit the staging buffers
-    const uint64_t chunk_cap = 256ull << 20;
+    // staged path: walk the valid lines in chunks.  Host buffers are pageable (the Java side hands over a
+    // mapped file and a heap array), so a copy blocks the thread that issues it; the copies of chunk i+1
+    // (host -> device, this thread) and of chunk i-1 (device -> host, a helper thread) therefore run on
+    // their own streams around the kernels of chunk i, and PCIe carries both directions at once.
+    const uint64_t chunk_cap = (uint64_t)c->opt_stage_chunk_mb << 20;
     uint64_t lines_per_chunk = chunk_cap / (nfft * out_esz);
     const uint64_t by_in = chunk_cap > nfft * bps ? (chunk_cap - nfft * bps) / ((uint64_t)hop * bps) + 1 : 1;
     if (by_in < lines_per_chunk) lines_per_chunk = by_in;
     if (lines_per_chunk == 0) lines_per_chunk = 1;
-    for (uint64_t l0 = 0; l0 < n_valid; l0 += lines_per_chunk) {
-        const uint64_t nl = (n_valid - l0 < lines_per_chunk) ? n_valid - l0 : lines_per_chunk;
-        const uint64_t in_off = start_byte + l0 * hop * bps, in_len = ((nl - 1) * hop + nfft) * bps;
-        const uint8_t *d_in;
-        if (iq_on_device) {
-            d_in = static_cast<const uint8_t *>(iq) + in_off;
-            if (reinterpret_cast<uintptr_t>(d_in) % component_bytes(dt) != 0)
-                return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
-        } else {
+    if (lines_per_chunk > n_valid && n_valid) lines_per_chunk = n_valid;
+    // slot strides of the two-deep staging buffers (256-byte multiples keep every slot aligned)
+    const uint64_t in_chunk_bytes = ((((lines_per_chunk - 1) * hop + nfft) * bps) + 255) & ~255ull,
+                   out_chunk_bytes = (lines_per_chunk * nfft * out_esz + 255) & ~255ull;
+    if (iq_on_device && n_valid &&
+        reinterpret_cast<uintptr_t>(static_cast<const uint8_t *>(iq) + start_byte) % component_bytes(dt) != 0)
+        return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
+    const uint64_t n_chunks = n_valid ? (n_valid + lines_per_chunk - 1) / lines_per_chunk : 0;
+    const uint64_t slots = n_chunks > 1 ? 2 : 1;
+    if (n_chunks == 1) {  // everything fits one chunk (every interactive call): one stream, no helper, least latency
+        const uint64_t in_len = ((n_valid - 1) * hop + nfft) * bps;
+        const uint8_t *d_in = static_cast<const uint8_t *>(iq) + start_byte;
+        if (!iq_on_device) {
             st = grow(c, &c->stage_in, &c->stage_in_bytes, in_len);
             if (st != SPEC_OK) return st;
-            HIP_TRY(c, hipMemcpyAsync(c->stage_in, static_cast<const uint8_t *>(iq) + in_off, in_len,
-                                      hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->stage_in, d_in, in_len, hipMemcpyHostToDevice, c->stream));
             d_in = static_cast<const uint8_t *>(c->stage_in);
         }
-        void *d_out;
-        if (out_on_device) {
-            d_out = static_cast<uint8_t *>(out) + l0 * nfft * out_esz;
-        } else {
-            st = grow(c, &c->stage_out, &c->stage_out_bytes, nl * nfft * out_esz);
+        void *d_out = out;
+        if (!out_on_device) {
+            st = grow(c, &c->stage_out, &c->stage_out_bytes, n_valid * nfft * out_esz);
             if (st != SPEC_OK) return st;
             d_out = c->stage_out;
         }
-        st = run_lines(c, d_in, dt, log2n, hop, nl, window, out_fmt, d_out);
+        st = run_lines(c, d_in, dt, log2n, hop, n_valid, window, out_fmt, d_out);
         if (st != SPEC_OK) return st;
         if (!out_on_device)
-            HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t *>(out) + l0 * nfft * out_esz, d_out, nl * nfft * out_esz,
-                                      hipMemcpyDeviceToHost, c->stream));
-        if (!iq_on_device || !out_on_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpyAsync(out, d_out, n_valid * nfft * out_esz, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    if (n_chunks > 1) {
+        if (!iq_on_device) { st = grow(c, &c->stage_in, &c->stage_in_bytes, slots * in_chunk_bytes); if (st != SPEC_OK) return st; }
+        if (!out_on_device) { st = grow(c, &c->stage_out, &c->stage_out_bytes, slots * out_chunk_bytes); if (st != SPEC_OK) return st; }
+        if (!c->s_in) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+            }
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // earlier work on the staging buffers
+    }
+    struct OutJob { uint64_t l0, nl; int slot; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<OutJob> jobs;
+    bool closing = false, slot_busy[2] = {false, false};
+    hipError_t worker_err = hipSuccess;
+    const bool threaded = !out_on_device && n_chunks > 1;
+    uint8_t *const h_out = static_cast<uint8_t *>(out);
+    auto copy_out = [&](const OutJob &j) -> hipError_t {  // device -> host of one finished chunk
+        hipError_t e = hipStreamWaitEvent(c->s_out, c->ev_done[j.slot], 0);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(h_out + j.l0 * nfft * out_esz, static_cast<uint8_t *>(c->stage_out) + j.slot * out_chunk_bytes,
+                               j.nl * nfft * out_esz, hipMemcpyDeviceToHost, c->s_out);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->s_out);
+        return e;
+    };
+    std::thread worker;
+    if (threaded)
+        worker = std::thread([&] {
+            (void)hipSetDevice(c->device);
+            for (;;) {
+                OutJob j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !jobs.empty() || closing; });
+                    if (jobs.empty()) return;
+                    j = jobs.front();
+                    jobs.pop_front();
+                }
+                const hipError_t e = copy_out(j);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (e != hipSuccess && worker_err == hipSuccess) worker_err = e;
+                    slot_busy[j.slot] = false;
+                }
+                cv.notify_all();
+            }
+        });
+    spec_status pst = SPEC_OK;
+    hipError_t perr = hipSuccess;
+    uint64_t chunk = 0;
+    for (uint64_t l0 = 0; l0 < n_valid && n_chunks > 1; l0 += lines_per_chunk, ++chunk) {
+        const uint64_t nl = (n_valid - l0 < lines_per_chunk) ? n_valid - l0 : lines_per_chunk;
+        const uint64_t in_off = start_byte + l0 * hop * bps, in_len = ((nl - 1) * hop + nfft) * bps;
+        const int slot = (int)(chunk & 1);
+        if (threaded) {  // the output slot must have been drained (chunk - 2)
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !slot_busy[slot]; });
+            if (worker_err != hipSuccess) break;
+        }
+        const uint8_t *d_in;
+        if (iq_on_device) {
+            d_in = static_cast<const uint8_t *>(iq) + in_off;
+        } else {
+            uint8_t *dst = static_cast<uint8_t *>(c->stage_in) + slot * in_chunk_bytes;
+            if (chunk >= 2) perr = hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0);  // kernels of chunk - 2 have read the slot
+            if (perr == hipSuccess)
+                perr = hipMemcpyAsync(dst, static_cast<const uint8_t *>(iq) + in_off, in_len, hipMemcpyHostToDevice, c->s_in);
+            if (perr == hipSuccess) perr = hipEventRecord(c->ev_in[slot], c->s_in);
+            if (perr == hipSuccess) perr = hipStreamWaitEvent(c->stream, c->ev_in[slot], 0);
+            if (perr != hipSuccess) break;
+            d_in = dst;
+        }
+        void *d_out = out_on_device ? static_cast<void *>(h_out + l0 * nfft * out_esz)
+                                    : static_cast<void *>(static_cast<uint8_t *>(c->stage_out) + slot * out_chunk_bytes);
+        pst = run_lines(c, d_in, dt, log2n, hop, nl, window, out_fmt, d_out);
+        if (pst != SPEC_OK) break;
+        perr = hipEventRecord(c->ev_done[slot], c->stream);
+        if (perr != hipSuccess) break;
+        if (!out_on_device) {
+            const OutJob j{l0, nl, slot};
+            if (threaded) {
+                { std::lock_guard<std::mutex> lk(mu); slot_busy[slot] = true; jobs.push_back(j); }
+                cv.notify_all();
+            } else {
+                perr = copy_out(j);
+                if (perr != hipSuccess) break;
+            }
+        }
+    }
+    if (threaded) {  // always join the helper before this frame goes away
+        { std::lock_guard<std::mutex> lk(mu); closing = true; }
+        cv.notify_all();
+        worker.join();
+    }
+    if (n_chunks > 1) {  // the staging buffers are free again, the events consumed
+        (void)hipStreamSynchronize(c->s_in);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (pst != SPEC_OK) return pst;
+    if (perr == hipSuccess) perr = worker_err;
+    if (perr != hipSuccess)
+        return fail(c, perr == hipErrorOutOfMemory ? SPEC_ENOMEM : SPEC_EDEVICE, "staging pipeline: %s", hipGetErrorString(perr));
     if (n_valid < n_lines) {  // MC:994-998
         const uint64_t n = (n_lines - n_valid) * nfft;
         if (out_on_device) {

@@ -160,7 +160,13 @@ class SpectralService:
                 int(n_lines), window, out_fmt, float(eof_fill), out.data_ptr(), 1))
             return out
         b = _host_bytes(buffer)
-        res = np.empty((int(n_lines), int(nfft)), dtype=np_dt)
+        if out is None:
+            res = np.empty((int(n_lines), int(nfft)), dtype=np_dt)
+        else:
+            res = out
+            if (not isinstance(res, np.ndarray) or res.dtype != np_dt or res.size < n_lines * nfft
+                    or not res.flags.c_contiguous):
+                raise ValueError("out array has the wrong dtype/size")
         self._check(self._lib.spec_waterfall(
             self._ctx, b.ctypes.data, 0, b.size, int(start_byte), dt, int(nfft), hop, int(n_lines),
             window, out_fmt, float(eof_fill), res.ctypes.data, 0))

@@ -398,3 +398,35 @@ def test_two_contexts_two_streams(oracle):
         t.join()
     for got, ref, nfft in results.values():
         check_fp32(got, ref, nfft)
+
+
+# ---- host-buffer pipeline (two-deep staging, copy-in / kernels / copy-out overlapped) -----------------
+@pytest.mark.parametrize("datatype,nfft,hop", [("ci16_le", 1024, 512), ("cf32_le", 4096, 4096), ("cf64_le", 256, 100)])
+@pytest.mark.parametrize("chunk_mb", [1, 64])
+def test_host_pipeline_matches_device_path(svc, datatype, nfft, hop, chunk_mb):
+    """Many small chunks (1 MiB) force every slot / event / helper-thread hand-off of the staged path;
+    the result must equal the single-launch device-resident path bit for bit, EOF lines included."""
+    import torch
+    n_samples = 700_000
+    iq = svc.synth_iq(datatype, 77, 0, n_samples)
+    n_lines = (n_samples - nfft) // hop + 1 + 3   # + three lines past the end (MC:994-998)
+    fmt = sa.OUT_DB20_F64 if datatype.startswith("cf64") else sa.OUT_DB20_F32
+    ref = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=fmt)
+    torch.cuda.synchronize()
+    svc.set_option("stage_chunk_mb", chunk_mb)
+    try:
+        host = iq.cpu().numpy()
+        got = svc.compute_waterfall(host, 0, nfft, datatype, n_lines, hop=hop, out_fmt=fmt)      # host -> host
+        assert np.array_equal(got, ref.cpu().numpy())
+        dev_out = torch.empty_like(ref)
+        s = svc
+        s._check(s._lib.spec_waterfall(s._ctx, host.ctypes.data, 0, host.size, 0, sa.dtype_from_sigmf(datatype), nfft, hop,
+                                       n_lines, sa.WIN_RECT, fmt, -150.0, dev_out.data_ptr(), 1))  # host -> device
+        torch.cuda.synchronize()
+        assert torch.equal(dev_out, ref)
+        out_h = np.empty(ref.shape, dtype=got.dtype)
+        s._check(s._lib.spec_waterfall(s._ctx, iq.data_ptr(), 1, iq.numel(), 0, sa.dtype_from_sigmf(datatype), nfft, hop,
+                                       n_lines, sa.WIN_RECT, fmt, -150.0, out_h.ctypes.data, 0))   # device -> host
+        assert np.array_equal(out_h, got)
+    finally:
+        svc.set_option("stage_chunk_mb", 64)
