@@ -229,6 +229,8 @@ template <int L> __device__ __forceinline__ void v2_sync() {
 template <int L, int PASS = 0>
 __device__ __forceinline__ void v2_fft(v2f (&v)[Plan2<L>::E], int t, v2f *lds, const v2f *tab, v2f (&twl)[16]) {
     using PL = Plan2<L>;
+    // SPEC_ABL_*: ablation builds of tools/ablate.sh (one stage removed, results wrong by construction,
+    // DESIGN.md 4.7); never defined in a product build
 #ifndef SPEC_ABL_NOFFT
     v2_pass<L, PASS>(v, t, tab, twl);
 #endif
