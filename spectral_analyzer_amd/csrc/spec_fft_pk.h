@@ -50,15 +50,6 @@ __device__ __forceinline__ void pk_dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
     x1 = pk_add_mi(t1, d);   // t1 + (-i) d
     x3 = pk_sub_mi(t1, d);   // t1 - (-i) d
 }
-// pk_dft4 with the third input still to be multiplied by -i (W16^4 folded in)
-__device__ __forceinline__ void pk_dft4_rot2(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
-    const v2f t0 = pk_add_mi(x0, x2), t1 = pk_sub_mi(x0, x2), t2 = x1 + x3, d = x1 - x3;
-    x0 = t0 + t2;
-    x2 = t0 - t2;
-    x1 = pk_add_mi(t1, d);
-    x3 = pk_sub_mi(t1, d);
-}
-
 // |a|^2 with scalar mul + fma: two instructions per bin.  (Left as v2f arithmetic hipcc packs two
 // bins per v_pk_mul_f32 and then spends four v_mov on the transposition: 3.5 per bin.)
 __device__ __forceinline__ float pk_norm(v2f a) { return __builtin_fmaf(a.x, a.x, a.y * a.y); }
@@ -74,17 +65,19 @@ __device__ __forceinline__ void pk_dft8(v2f (&u)[8]) {
     constexpr float h = 0.70710678118654752440f;
     pk_dft4(u[0], u[2], u[4], u[6]);  // A0[k1] -> slots 0,2,4,6
     pk_dft4(u[1], u[3], u[5], u[7]);  // A1[k1] -> slots 1,3,5,7
-    const v2f a1 = pk_add_mi(u[3], u[3]) * v2f{h, h};    // A1[1] W8^1 = h(1 - i)
-    const v2f a3 = pk_sub_mi(u[7], u[7]) * v2f{-h, -h};  // A1[3] W8^3 = -h(1 + i)
+    // A1[1] W8^1 = h(1 - i) A1[1] and A1[3] W8^3 = -h(1 + i) A1[3]: the factor h rides in the FMA of the
+    // final additions instead of a multiply of its own
+    const v2f q1 = pk_add_mi(u[3], u[3]);                // (1 - i) A1[1]
+    const v2f q3 = pk_sub_mi(u[7], u[7]);                // (1 + i) A1[3]
     v2f y[8];
     y[0] = u[0] + u[1];
     y[4] = u[0] - u[1];
-    y[1] = u[2] + a1;
-    y[5] = u[2] - a1;
+    y[1] = __builtin_elementwise_fma(q1, v2f{h, h}, u[2]);
+    y[5] = __builtin_elementwise_fma(q1, v2f{-h, -h}, u[2]);
     y[2] = pk_add_mi(u[4], u[5]);                        // A1[2] W8^2 = -i folded in
     y[6] = pk_sub_mi(u[4], u[5]);
-    y[3] = u[6] + a3;
-    y[7] = u[6] - a3;
+    y[3] = __builtin_elementwise_fma(q3, v2f{-h, -h}, u[6]);
+    y[7] = __builtin_elementwise_fma(q3, v2f{h, h}, u[6]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) u[k] = y[k];
 }
@@ -99,20 +92,44 @@ __device__ __forceinline__ void pk_dft16(v2f (&u)[16]) {
     pk_dft4(u[1], u[5], u[9], u[13]);
     pk_dft4(u[2], u[6], u[10], u[14]);
     pk_dft4(u[3], u[7], u[11], u[15]);
-    // slot 4*k1 + n2 holds A[n2][k1]; multiply by W16^(n2*k1)
+    // slot 4*k1 + n2 holds A[n2][k1]; multiply by W16^(n2*k1).  The four factors of modulus h,
+    // W16^2 = h(1 - i) and W16^6 = -h(1 + i), are applied as (1 -+ i) here and as +-h inside the FMAs of
+    // the second-stage butterflies: no multiply of their own
     u[5] = pk_cmul_const(u[5], c1, -s1);                  // W16^1 = c1 - i s1
-    u[6] = pk_add_mi(u[6], u[6]) * v2f{h, h};             // W16^2 = h(1 - i)
+    const v2f q6 = pk_add_mi(u[6], u[6]);                 // (1 - i) u6,  u6 W16^2 = h q6
     u[7] = pk_cmul_const(u[7], s1, -c1);                  // W16^3 = s1 - i c1
-    u[9] = pk_add_mi(u[9], u[9]) * v2f{h, h};             // W16^2
-    /* u[10] *= W16^4 = -i : folded into the third pk_dft4 below */
-    u[11] = pk_sub_mi(u[11], u[11]) * v2f{-h, -h};        // W16^6 = -h(1 + i)
+    const v2f q9 = pk_add_mi(u[9], u[9]);                 // u9 W16^2 = h q9
+    /* u[10] *= W16^4 = -i : folded into the third butterfly below */
+    const v2f q11 = pk_sub_mi(u[11], u[11]);              // (1 + i) u11, u11 W16^6 = -h q11
     u[13] = pk_cmul_const(u[13], s1, -c1);                // W16^3
-    u[14] = pk_sub_mi(u[14], u[14]) * v2f{-h, -h};        // W16^6
+    const v2f q14 = pk_sub_mi(u[14], u[14]);              // u14 W16^6 = -h q14
     u[15] = pk_cmul_const(u[15], -c1, s1);                // W16^9 = -W16^1
+    constexpr v2f ph{h, h}, mh{-h, -h};
     pk_dft4(u[0], u[1], u[2], u[3]);
-    pk_dft4(u[4], u[5], u[6], u[7]);
-    pk_dft4_rot2(u[8], u[9], u[10], u[11]);
-    pk_dft4(u[12], u[13], u[14], u[15]);
+    {   // dft4(u4, u5, h q6, u7)
+        const v2f t0 = __builtin_elementwise_fma(q6, ph, u[4]), t1 = __builtin_elementwise_fma(q6, mh, u[4]);
+        const v2f t2 = u[5] + u[7], d = u[5] - u[7];
+        u[4] = t0 + t2;
+        u[6] = t0 - t2;
+        u[5] = pk_add_mi(t1, d);
+        u[7] = pk_sub_mi(t1, d);
+    }
+    {   // dft4(u8, h q9, -i u10, -h q11):  x1 + x3 = h (q9 - q11),  x1 - x3 = h (q9 + q11)
+        const v2f t0 = pk_add_mi(u[8], u[10]), t1 = pk_sub_mi(u[8], u[10]);
+        const v2f sm = q9 - q11, sp = q9 + q11;
+        u[8] = __builtin_elementwise_fma(sm, ph, t0);
+        u[10] = __builtin_elementwise_fma(sm, mh, t0);
+        u[9] = __builtin_elementwise_fma(pk_swap(sp), v2f{h, -h}, t1);    // t1 + (-i) h sp
+        u[11] = __builtin_elementwise_fma(pk_swap(sp), v2f{-h, h}, t1);   // t1 - (-i) h sp
+    }
+    {   // dft4(u12, u13, -h q14, u15)
+        const v2f t0 = __builtin_elementwise_fma(q14, mh, u[12]), t1 = __builtin_elementwise_fma(q14, ph, u[12]);
+        const v2f t2 = u[13] + u[15], d = u[13] - u[15];
+        u[12] = t0 + t2;
+        u[14] = t0 - t2;
+        u[13] = pk_add_mi(t1, d);
+        u[15] = pk_sub_mi(t1, d);
+    }
     // slot 4*k1 + k2 holds X[k1 + 4*k2]: transpose to natural order (pure renaming)
     v2f y[16];
 #pragma unroll
