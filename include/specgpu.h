@@ -112,7 +112,9 @@ void *spec_stream(const spec_ctx *ctx);
  *   "force_generic" = 1  route every request through the generic (scalar-math) kernels
  *   "lines_per_wg"  = n  consecutive lines walked by one sub-line / workgroup (0 = automatic)
  *   "large_chunk_mb" = m scratch size of the four-step path (nfft >= 32768; default 1024 MiB)
- *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB) */
+ *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
+ *   "readahead_lines" = n slices spec_compute_magnitudes computes per launch once its calls walk a buffer
+ *                     slice by slice (default 256; 0 or 1 = every call is its own launch) */
 spec_status spec_set_option(spec_ctx *ctx, const char *key, int64_t value);
 
 /* ---- datatype table ------------------------------------------------------ */
@@ -141,7 +143,12 @@ uint64_t spec_count_lines(uint64_t n_bytes, uint64_t start_byte, spec_dtype dt,
  * ByteOrder (SigMfHelper.java:87-91).  Writes nfft doubles to `out`
  * (index 0 = -fs/2).  The whole pipeline runs in fp64 on the GPU.
  * Errors: non power-of-two nfft -> SPEC_EINVAL; start_byte + nfft*bps >
- * capacity -> SPEC_ERANGE (the reference's getters would throw). */
+ * capacity -> SPEC_ERANGE (the reference's getters would throw).
+ * The reference calls this once per slice, slice after slice (MC:982-993).  When a call continues
+ * the previous one (start_byte advanced by exactly one slice of the same buffer), the library
+ * transforms the next "readahead_lines" slices in the same launch and serves the following calls
+ * from that batch -- only while the caller's input bytes still compare equal to the bytes the
+ * batch was computed from, so the returned line is always the transform of the current bytes. */
 spec_status spec_compute_magnitudes(spec_ctx *ctx, const void *buffer, uint64_t capacity,
                                     int64_t start_byte, uint32_t nfft, const char *datatype,
                                     int big_endian, double *out);

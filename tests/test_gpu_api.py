@@ -430,3 +430,37 @@ def test_host_pipeline_matches_device_path(svc, datatype, nfft, hop, chunk_mb):
         assert np.array_equal(out_h, got)
     finally:
         svc.set_option("stage_chunk_mb", 64)
+
+
+# ---- read-ahead of the per-slice call (the unmodified MainController loop, MC:982-993) --------------
+@pytest.mark.parametrize("datatype,nfft", [("ci16_le", 1024), ("cf32_le", 4096), ("cu8", 256), ("cf64_be", 512)])
+def test_compute_magnitudes_readahead_is_transparent(svc, oracle, datatype, nfft):
+    """Walk a buffer slice by slice as the reference loop does: the batched read-ahead must return exactly
+    what one launch per call returns, notice bytes that changed under it, and keep the error behaviour."""
+    bps = oracle.bytes_per_sample(datatype)
+    n_slices = 700
+    iq = oracle.synth_iq(datatype, 5, 0, n_slices * nfft + 17).copy()
+    svc.set_option("readahead_lines", 0)
+    plain = [svc.compute_magnitudes(iq, t * nfft * bps, nfft, datatype) for t in range(0, n_slices, 37)]
+    svc.set_option("readahead_lines", 256)
+    try:
+        walked = [svc.compute_magnitudes(iq, t * nfft * bps, nfft, datatype) for t in range(n_slices)]
+        for k, t in enumerate(range(0, n_slices, 37)):
+            assert np.array_equal(walked[t], plain[k]), t
+        # bytes change between two calls of a walk: the cached line must not be served
+        a = svc.compute_magnitudes(iq, 10 * nfft * bps, nfft, datatype)
+        b = svc.compute_magnitudes(iq, 11 * nfft * bps, nfft, datatype)      # sequential: batch computed here
+        iq[12 * nfft * bps: 13 * nfft * bps] = oracle.synth_iq(datatype, 99, 0, nfft)
+        c = svc.compute_magnitudes(iq, 12 * nfft * bps, nfft, datatype)
+        assert np.array_equal(a, walked[10]) and np.array_equal(b, walked[11]) and not np.array_equal(c, walked[12])
+        check_fp64(c[None, :], oracle.compute_magnitudes(iq, 12 * nfft * bps, nfft, datatype, cf64_decode=True)[None, :])
+        d = svc.compute_magnitudes(iq, 13 * nfft * bps, nfft, datatype)      # unchanged slice, still cached
+        assert np.array_equal(d, walked[13])
+        # the walk runs into the end of the buffer: last whole slice fine, the next one out of range
+        last = (iq.size // (nfft * bps)) - 1
+        for t in range(last - 3, last + 1):
+            svc.compute_magnitudes(iq, t * nfft * bps, nfft, datatype)
+        with pytest.raises(IndexError):
+            svc.compute_magnitudes(iq, (last + 1) * nfft * bps, nfft, datatype)
+    finally:
+        svc.set_option("readahead_lines", 256)

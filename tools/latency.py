@@ -23,5 +23,15 @@ for dt, nfft in (("ci16_le", 1024), ("cf32_le", 4096), ("cf32_le", 65536)):
     t0 = time.perf_counter()
     for i in range(3): so.waterfall(iq, 0, dt, nfft, nfft, W)
     cpu = (time.perf_counter() - t0) / 3
+    # the UNMODIFIED reference loop (MC:982-993): one computeMagnitudes call per slice, slice after slice
+    bps = so.bytes_per_sample(dt)
+    walk = {}
+    for ra in (0, 256):
+        svc.set_option("readahead_lines", ra)
+        for _ in range(2): [svc.compute_magnitudes(iq, t * nfft * bps, nfft, dt) for t in range(W)]
+        t0 = time.perf_counter()
+        for _ in range(3): [svc.compute_magnitudes(iq, t * nfft * bps, nfft, dt) for t in range(W)]
+        walk[ra] = (time.perf_counter() - t0) / 3
     print("%s nfft %5d: computeMagnitudes %.1f us/call | %d-line redraw: batched %.2f ms, batched+render %.2f ms, "
-          "%d single calls %.1f ms, CPU oracle 1 thread %.1f ms" % (dt, nfft, one * 1e6, W, wf * 1e3, wr * 1e3, W, one * W * 1e3, cpu * 1e3))
+          "%d per-slice calls %.1f ms without / %.2f ms with read-ahead, CPU oracle 1 thread %.1f ms"
+          % (dt, nfft, one * 1e6, W, wf * 1e3, wr * 1e3, W, walk[0] * 1e3, walk[256] * 1e3, cpu * 1e3))
