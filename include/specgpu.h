@@ -113,6 +113,8 @@ void *spec_stream(const spec_ctx *ctx);
  *   "lines_per_wg"  = n  consecutive lines walked by one sub-line / workgroup (0 = automatic)
  *   "large_chunk_mb" = m scratch size of the four-step path (nfft >= 32768; default 1024 MiB)
  *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
+ *   "render_fused" = 0 | 1   spec_waterfall_render stores only the bins the image samples (default 1; 0 = full
+ *                     dB tile, then the colour kernel: the two forms give identical pixels)
  *   "readahead_lines" = n slices spec_compute_magnitudes computes per launch once its calls walk a buffer
  *                     slice by slice (default 256; 0 or 1 = every call is its own launch) */
 spec_status spec_set_option(spec_ctx *ctx, const char *key, int64_t value);

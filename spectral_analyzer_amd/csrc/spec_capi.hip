@@ -52,7 +52,9 @@ struct spec_ctx {
         std::vector<uint8_t> in; std::vector<double> out;
         const void *last_buf = nullptr; uint64_t last_start = 0; int last_dt = -1; uint32_t last_nfft = 0;
     } ra;
-    int64_t opt_readahead_lines = 256;
+    int64_t opt_readahead_lines = 256, opt_render_fused = 1;
+    // spec_waterfall_render: device table "pixel row of bin k" of the last (nfft, height) pair
+    int32_t *sel_dev = nullptr; uint32_t sel_nfft = 0, sel_height = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -186,6 +188,7 @@ void spec_destroy(spec_ctx *c) {
     (void)hipFree(c->stage_out);
     (void)hipFree(c->scratch);
     (void)hipFree(c->scratch2);
+    (void)hipFree(c->sel_dev);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
         if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
@@ -212,6 +215,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "lines_per_wg")) c->opt_lines_per_wg = value < 0 ? 0 : value;
     else if (!strcmp(key, "large_chunk_mb")) c->opt_large_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
+    else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
     else if (!strcmp(key, "readahead_lines")) { c->opt_readahead_lines = value < 0 ? 0 : value; c->ra.n = 0; }
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
     return SPEC_OK;
@@ -305,8 +309,11 @@ static uint32_t pick_lines_per_wg(uint64_t n_lines, int lpw) {
 }
 
 // launch the spectrogram kernel(s) for lines that lie fully inside the buffer
+// d_sel != nullptr: "selected bins" mode -- rows of `row` floats, bin k at column d_sel[k] (callers check
+// v2_sel_applicable first)
 static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt, int log2n, uint32_t hop,
-                             uint64_t n_lines, spec_window window, spec_out_fmt fmt, void *d_out) {
+                             uint64_t n_lines, spec_window window, spec_out_fmt fmt, void *d_out,
+                             const int32_t *d_sel = nullptr, uint32_t row = 0) {
     if (n_lines == 0) return SPEC_OK;
     const bool f64 = fmt >= SPEC_OUT_DB20_F64 || dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
     int l1 = 0, l2 = 0;
@@ -320,6 +327,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     a.kind = kind_of(dt, c->flags);
     a.be = is_be(dt);
     a.out_fmt = (int)fmt;
+    if (d_sel && (f64 || fmt != SPEC_OUT_DB20_F32 || c->opt_force_generic || !v2_sel_applicable(log2n, a.kind, a.be, n_lines, hop)))
+        return fail(c, SPEC_EUNSUPPORTED, "selected-bin output is not available for this configuration");
     // the four-step path takes its inter-step twiddles from the fp64 W_N table whatever the precision
     spec_status st = get_twiddles(c, log2n, large ? true : f64, &a.tw);
     if (st != SPEC_OK) return st;
@@ -361,8 +370,9 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             const uint64_t max_lines = 0x7FFFFFFFull;  // 32-bit line index inside one launch
             a.n_lines = rem < max_lines ? rem : max_lines;
             a.iq = d_first + done * (uint64_t)hop * a.bps;
-            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
-            hipError_t e = launch_v2_spectro(a, log2n, (uint32_t)run, c->stream);
+            a.out = static_cast<uint8_t *>(d_out) + done * (d_sel ? row : nfft) * out_esz;
+            hipError_t e = d_sel ? launch_v2_spectro_sel(a, log2n, (uint32_t)run, d_sel, row, c->stream)
+                                 : launch_v2_spectro(a, log2n, (uint32_t)run, c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "spectrogram launch: %s", hipGetErrorString(e));
             done += a.n_lines;
         }
@@ -400,9 +410,10 @@ static spec_status check_common(spec_ctx *c, const void *iq, const void *out, in
 
 extern "C" {
 
-spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
-                           spec_dtype dt, uint32_t nfft, uint32_t hop, uint64_t n_lines, spec_window window,
-                           spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device) {
+static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
+                                  spec_dtype dt, uint32_t nfft, uint32_t hop, uint64_t n_lines, spec_window window,
+                                  spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device,
+                                  const int32_t *d_sel, uint32_t sel_row) {
     int log2n = 0;
     spec_status st = check_common(c, iq, out, dt, nfft, hop, window, &log2n);
     if (st != SPEC_OK) return st;
@@ -410,6 +421,7 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
     if (n_lines == 0) return SPEC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t bps = spec_bytes_per_sample(dt), out_esz = out_fmt >= SPEC_OUT_DB20_F64 ? 8 : 4;
+    const uint64_t row = d_sel ? sel_row : nfft;  // elements per output line
     // MainController.java:987 -- lines whose last byte is inside the buffer
     uint64_t n_valid = spec_count_lines(n_bytes, start_byte, dt, nfft, hop);
     if (n_valid > n_lines) n_valid = n_lines;
@@ -425,10 +437,10 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
         const uint8_t *first = static_cast<const uint8_t *>(iq) + start_byte;
         if (n_valid && (reinterpret_cast<uintptr_t>(first) % component_bytes(dt)) != 0)
             return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
-        st = run_lines(c, first, dt, log2n, hop, n_valid, window, out_fmt, out);
+        st = run_lines(c, first, dt, log2n, hop, n_valid, window, out_fmt, out, d_sel, sel_row);
         if (st != SPEC_OK) return st;
         if (n_valid < n_lines) {  // MC:994-998
-            hipError_t e = launch_fill(static_cast<uint8_t *>(out) + n_valid * nfft * out_esz, (n_lines - n_valid) * nfft,
+            hipError_t e = launch_fill(static_cast<uint8_t *>(out) + n_valid * row * out_esz, (n_lines - n_valid) * row,
                                        eof_fill, out_esz == 8, c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "fill launch: %s", hipGetErrorString(e));
         }
@@ -440,14 +452,14 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
     // (host -> device, this thread) and of chunk i-1 (device -> host, a helper thread) therefore run on
     // their own streams around the kernels of chunk i, and PCIe carries both directions at once.
     const uint64_t chunk_cap = (uint64_t)c->opt_stage_chunk_mb << 20;
-    uint64_t lines_per_chunk = chunk_cap / (nfft * out_esz);
+    uint64_t lines_per_chunk = chunk_cap / (row * out_esz);
     const uint64_t by_in = chunk_cap > nfft * bps ? (chunk_cap - nfft * bps) / ((uint64_t)hop * bps) + 1 : 1;
     if (by_in < lines_per_chunk) lines_per_chunk = by_in;
     if (lines_per_chunk == 0) lines_per_chunk = 1;
     if (lines_per_chunk > n_valid && n_valid) lines_per_chunk = n_valid;
     // slot strides of the two-deep staging buffers (256-byte multiples keep every slot aligned)
     const uint64_t in_chunk_bytes = ((((lines_per_chunk - 1) * hop + nfft) * bps) + 255) & ~255ull,
-                   out_chunk_bytes = (lines_per_chunk * nfft * out_esz + 255) & ~255ull;
+                   out_chunk_bytes = (lines_per_chunk * row * out_esz + 255) & ~255ull;
     if (iq_on_device && n_valid &&
         reinterpret_cast<uintptr_t>(static_cast<const uint8_t *>(iq) + start_byte) % component_bytes(dt) != 0)
         return fail(c, SPEC_EINVAL, "device input is not aligned to its %u-byte components", component_bytes(dt));
@@ -464,14 +476,14 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
         }
         void *d_out = out;
         if (!out_on_device) {
-            st = grow(c, &c->stage_out, &c->stage_out_bytes, n_valid * nfft * out_esz);
+            st = grow(c, &c->stage_out, &c->stage_out_bytes, n_valid * row * out_esz);
             if (st != SPEC_OK) return st;
             d_out = c->stage_out;
         }
-        st = run_lines(c, d_in, dt, log2n, hop, n_valid, window, out_fmt, d_out);
+        st = run_lines(c, d_in, dt, log2n, hop, n_valid, window, out_fmt, d_out, d_sel, sel_row);
         if (st != SPEC_OK) return st;
         if (!out_on_device)
-            HIP_TRY(c, hipMemcpyAsync(out, d_out, n_valid * nfft * out_esz, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(out, d_out, n_valid * row * out_esz, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     if (n_chunks > 1) {
@@ -498,8 +510,8 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
     auto copy_out = [&](const OutJob &j) -> hipError_t {  // device -> host of one finished chunk
         hipError_t e = hipStreamWaitEvent(c->s_out, c->ev_done[j.slot], 0);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(h_out + j.l0 * nfft * out_esz, static_cast<uint8_t *>(c->stage_out) + j.slot * out_chunk_bytes,
-                               j.nl * nfft * out_esz, hipMemcpyDeviceToHost, c->s_out);
+            e = hipMemcpyAsync(h_out + j.l0 * row * out_esz, static_cast<uint8_t *>(c->stage_out) + j.slot * out_chunk_bytes,
+                               j.nl * row * out_esz, hipMemcpyDeviceToHost, c->s_out);
         if (e == hipSuccess) e = hipStreamSynchronize(c->s_out);
         return e;
     };
@@ -550,9 +562,9 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
             if (perr != hipSuccess) break;
             d_in = dst;
         }
-        void *d_out = out_on_device ? static_cast<void *>(h_out + l0 * nfft * out_esz)
+        void *d_out = out_on_device ? static_cast<void *>(h_out + l0 * row * out_esz)
                                     : static_cast<void *>(static_cast<uint8_t *>(c->stage_out) + slot * out_chunk_bytes);
-        pst = run_lines(c, d_in, dt, log2n, hop, nl, window, out_fmt, d_out);
+        pst = run_lines(c, d_in, dt, log2n, hop, nl, window, out_fmt, d_out, d_sel, sel_row);
         if (pst != SPEC_OK) break;
         perr = hipEventRecord(c->ev_done[slot], c->stream);
         if (perr != hipSuccess) break;
@@ -581,20 +593,27 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
     if (perr != hipSuccess)
         return fail(c, perr == hipErrorOutOfMemory ? SPEC_ENOMEM : SPEC_EDEVICE, "staging pipeline: %s", hipGetErrorString(perr));
     if (n_valid < n_lines) {  // MC:994-998
-        const uint64_t n = (n_lines - n_valid) * nfft;
+        const uint64_t n = (n_lines - n_valid) * row;
         if (out_on_device) {
-            hipError_t e = launch_fill(static_cast<uint8_t *>(out) + n_valid * nfft * out_esz, n, eof_fill, out_esz == 8,
+            hipError_t e = launch_fill(static_cast<uint8_t *>(out) + n_valid * row * out_esz, n, eof_fill, out_esz == 8,
                                        c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "fill launch: %s", hipGetErrorString(e));
         } else if (out_esz == 8) {
-            double *p = static_cast<double *>(out) + n_valid * nfft;
+            double *p = static_cast<double *>(out) + n_valid * row;
             for (uint64_t i = 0; i < n; ++i) p[i] = eof_fill;
         } else {
-            float *p = static_cast<float *>(out) + n_valid * nfft;
+            float *p = static_cast<float *>(out) + n_valid * row;
             for (uint64_t i = 0; i < n; ++i) p[i] = (float)eof_fill;
         }
     }
     return SPEC_OK;
+}
+
+spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
+                           spec_dtype dt, uint32_t nfft, uint32_t hop, uint64_t n_lines, spec_window window,
+                           spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device) {
+    return waterfall_impl(c, iq, iq_on_device, n_bytes, start_byte, dt, nfft, hop, n_lines, window, out_fmt, eof_fill, out,
+                          out_on_device, nullptr, 0);
 }
 
 spec_status spec_compute_magnitudes(spec_ctx *c, const void *buffer, uint64_t capacity, int64_t start_byte,
@@ -839,7 +858,7 @@ spec_status spec_render_spectrogram(spec_ctx *c, const float *tile, int tile_on_
         d_out = c->stage_out;
     }
     const double conversion = 10 * std::log10(fs / nfft) + 20 * std::log10((double)nfft);  // MC:1273-1274
-    hipError_t e = launch_render(d_tile, width, nfft, height, conversion, min_db, max_db, (int)colormap, d_out, c->stream);
+    hipError_t e = launch_render(d_tile, width, nfft, height, conversion, min_db, max_db, (int)colormap, 0, d_out, c->stream);
     if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "render launch: %s", hipGetErrorString(e));
     if (!out_on_device) {
         HIP_TRY(c, hipMemcpyAsync(bgra_out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -858,6 +877,54 @@ spec_status spec_waterfall_render(spec_ctx *c, const void *iq, int iq_on_device,
     if (!bgra_out) return fail(c, SPEC_EINVAL, "null buffer");
     if (n_lines == 0 || height == 0) return SPEC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    // Fused form: the image samples ONE bin per pixel row (MC:1280), so the FFT kernel stores only those
+    // `height` bins of every line (a compact [n_lines][height] tile) and the colour kernel reads that.
+    // Needs a kernel of the packed family with 16-point threads and a one-to-one bin -> row map.
+    if (c->opt_render_fused && !c->opt_force_generic && nfft >= 256 && nfft <= 4096 && (nfft & (nfft - 1)) == 0 &&
+        height <= nfft && dtype_valid(dt) && hop >= 1 && fs > 0 &&
+        (colormap == SPEC_CMAP_GRAYSCALE || colormap == SPEC_CMAP_HEATMAP) &&
+        v2_sel_applicable(ilog2(nfft), kind_of(dt, c->flags), is_be(dt), n_lines, hop)) {
+        std::vector<int32_t> sel(nfft, -1);
+        bool one_to_one = true;
+        for (uint32_t f = 0; f < height && one_to_one; ++f) {
+            const int bin = (int)((double)f / (double)height * (double)nfft);  // MC:1280, fftshifted index
+            const uint32_t k = ((uint32_t)bin + nfft / 2) & (nfft - 1);        // SS:78 undone
+            if (bin < 0 || (uint32_t)bin >= nfft || sel[k] >= 0) one_to_one = false; else sel[k] = (int32_t)f;
+        }
+        if (one_to_one) {
+            if (c->sel_nfft != nfft || c->sel_height != height) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (c->sel_nfft != nfft) {
+                    if (c->sel_dev) { (void)hipFree(c->sel_dev); c->sel_dev = nullptr; }
+                    c->sel_nfft = 0;
+                    HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&c->sel_dev), nfft * sizeof(int32_t)));
+                }
+                HIP_TRY(c, hipMemcpy(c->sel_dev, sel.data(), nfft * sizeof(int32_t), hipMemcpyHostToDevice));
+                c->sel_nfft = nfft; c->sel_height = height;
+            }
+            spec_status st = grow(c, &c->scratch2, &c->scratch2_bytes, (size_t)n_lines * height * sizeof(float));
+            if (st != SPEC_OK) return st;
+            st = waterfall_impl(c, iq, iq_on_device, n_bytes, start_byte, dt, nfft, hop, n_lines, window, SPEC_OUT_DB20_F32,
+                                -150.0, c->scratch2, 1, c->sel_dev, height);
+            if (st != SPEC_OK) return st;
+            const size_t out_bytes = (size_t)n_lines * height * 4;
+            void *d_out = bgra_out;
+            if (!out_on_device) {
+                st = grow(c, &c->stage_out, &c->stage_out_bytes, out_bytes);
+                if (st != SPEC_OK) return st;
+                d_out = c->stage_out;
+            }
+            const double conversion = 10 * std::log10(fs / nfft) + 20 * std::log10((double)nfft);  // MC:1273-1274
+            hipError_t e = launch_render(static_cast<const float *>(c->scratch2), n_lines, nfft, height, conversion, min_db,
+                                         max_db, (int)colormap, 1, d_out, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "render launch: %s", hipGetErrorString(e));
+            if (!out_on_device) {
+                HIP_TRY(c, hipMemcpyAsync(bgra_out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+            return SPEC_OK;
+        }
+    }
     // dB tile lives in the context's scratch2 and never crosses PCIe
     spec_status st = grow(c, &c->scratch2, &c->scratch2_bytes, (size_t)n_lines * nfft * sizeof(float));
     if (st != SPEC_OK) return st;

@@ -55,6 +55,9 @@ hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void
 bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, uint32_t hop);
 int v2_lpw(int log2n);  // sub-lines per workgroup
 hipError_t launch_v2_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream_t s);
+bool v2_sel_applicable(int log2n, int kind, int be, uint64_t n_lines, uint32_t hop);
+hipError_t launch_v2_spectro_sel(const WfArgs &w, int log2n, uint32_t run, const int32_t *sel, uint32_t out_stride,
+                                 hipStream_t s);
 hipError_t launch_v2_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t wgs_per_unit, hipStream_t s);
 
 hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);
@@ -64,8 +67,9 @@ hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t 
 // then scale / dB into psd_out
 hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint32_t nfft, double *acc, hipStream_t s);
 hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);
+// compact != 0: tile is [width][height] with column f = the bin pixel row f samples (launch_v2_spectro_sel)
 hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
-                         double min_db, double max_db, int colormap, void *bgra, hipStream_t s);
+                         double min_db, double max_db, int colormap, int compact, void *bgra, hipStream_t s);
 hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t first_sample,
                         uint64_t n_samples, hipStream_t s);
 

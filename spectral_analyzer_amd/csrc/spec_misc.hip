@@ -91,13 +91,15 @@ hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int
 // Java expressions operation by operation (double for the bin / normalisation, float for
 // Color.interpolate, round-half-up to 8 bits); the _rn intrinsics keep hipcc from fusing them.
 __global__ void render_kernel(const float *__restrict__ tile, uint32_t width, uint32_t nfft, uint32_t height,
-                              double conversion, double min_db, double max_db, int colormap,
+                              double conversion, double min_db, double max_db, int colormap, int compact,
                               uchar4 *__restrict__ out) {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= width) return;
     const uint32_t f = height - 1 - y;                                             // MC:1288
     const int bin = (int)__dmul_rn(__ddiv_rn((double)f, (double)height), (double)nfft);  // MC:1280
-    const double db = __dsub_rn((double)tile[(uint64_t)x * nfft + bin], conversion);     // MC:1283
+    // compact tile: the FFT kernel stored only the sampled bins, bin(f) at column f
+    const float tv = compact ? tile[(uint64_t)x * height + f] : tile[(uint64_t)x * nfft + bin];
+    const double db = __dsub_rn((double)tv, conversion);                                 // MC:1283
     double n = __ddiv_rn(__dsub_rn(db, min_db), __dsub_rn(max_db, min_db));        // MC:929
     n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);                                       // MC:930
     float r, g, b;
@@ -121,10 +123,10 @@ __global__ void render_kernel(const float *__restrict__ tile, uint32_t width, ui
 }
 
 hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
-                         double min_db, double max_db, int colormap, void *bgra, hipStream_t s) {
+                         double min_db, double max_db, int colormap, int compact, void *bgra, hipStream_t s) {
     if (width == 0 || height == 0) return hipSuccess;
     hipLaunchKernelGGL(render_kernel, dim3((width + 255) / 256, height), dim3(256), 0, s, tile, width, nfft, height,
-                       conversion, min_db, max_db, colormap, static_cast<uchar4 *>(bgra));
+                       conversion, min_db, max_db, colormap, compact, static_cast<uchar4 *>(bgra));
     return hipGetLastError();
 }
 

@@ -298,9 +298,13 @@ struct V2Args {
     void *out;              // spectrogram: float[n_lines][N]; Welch: float slabs [unit][wg*LPW + q][N]
     int out_fmt;
     int be;                 // big-endian components
+    const int32_t *sel;     // MODE 2: column of bin k (unshifted index) in the compact line, or -1
+    uint32_t out_stride;    // MODE 2: floats per compact line
 };
 
-// MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums
+// MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums; MODE 2: spectrogram
+// lines of which only the bins a later stage samples are stored (renderSpectrogram reads one bin per pixel
+// row, MC:1280): a compact line of out_stride floats, bin k at column sel[k]
 template <int L, int KIND, int SH, bool HAS_WIN, int MODE, bool BE, int OCC>
 __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     using PL = Plan2<L>;
@@ -365,6 +369,18 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
                                                 lines_wg * (uint32_t)N * 4u, 0x00020000);
         ovoff = (int)(q * a.run * (uint32_t)N * 4u) + t * 4;
     }
+    int pxo[MODE == 2 ? E : 1];  // MODE 2: byte offset of each of this thread's bins in its compact line
+    (void)pxo;
+    if constexpr (MODE == 2) {
+        dst = __builtin_amdgcn_make_buffer_rsrc(static_cast<float *>(a.out) + (uint64_t)line0 * a.out_stride, 0,
+                                                lines_wg * a.out_stride * 4u, 0x00020000);
+        ovoff = (int)(q * a.run * a.out_stride * 4u);
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int col = a.sel[t + m * T];
+            pxo[m] = col >= 0 ? ovoff + col * 4 : 0x7FFFFFFF;  // past the descriptor: the store is dropped
+        }
+    }
     // sub-lines whose run lies past the end read zeros and store nothing (descriptor bounds)
     const uint32_t my_first = q * a.run;
     const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
@@ -413,6 +429,13 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
             constexpr bool BOUNDED = KIND != K_CF32;
             if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, BOUNDED, E>(v, RW::SCALE, d);
             else v2_epilogue<false, BOUNDED, E>(v, RW::SCALE, d);
+            if constexpr (MODE == 2) {
+                const int row_off = (int)(line * a.out_stride * 4u);
+#pragma unroll
+                for (int m = 0; m < E; ++m)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d[m]), dst, pxo[m], row_off, ST_AUX);
+                return;
+            }
             const int out_off = (int)(line * (uint32_t)N * 4u);
 #ifdef SPEC_ABL_NOSTORE
             const bool do_store = d[0] == 123.456f;
@@ -452,7 +475,7 @@ hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
     // Minimum waves per SIMD asked of the register allocator, chosen so that the kernel does
     // not spill: about 104 VGPRs of FFT state + 32 (cf32) or 16 raw sample registers + 16 for a
     // window + 16 for Welch sums.  32-point threads (8192 / 16384 points) take the full 256.
-    constexpr int NEED = 104 + (KIND == K_CF32 ? 32 : 16) + (HAS_WIN ? 16 : 0) + (MODE == 1 ? 16 : 0);
+    constexpr int NEED = 104 + (KIND == K_CF32 ? 32 : 16) + (HAS_WIN ? 16 : 0) + (MODE != 0 ? 16 : 0);
 #ifdef SPEC_FORCE_OCC  // experiments only
     constexpr int WAVES_PER_SIMD = PL::E == 32 ? 2 : SPEC_FORCE_OCC;
 #else
@@ -478,7 +501,7 @@ template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hi
     if constexpr (WIDE) {  // big-endian files: one variant per mode (no register reuse), byte swap at decode
         if (a.be) {
             if constexpr (MODE == 1) return v2_launch1<L, KIND, 0, true, 1, true>(a, s);
-            else return a.win ? v2_launch1<L, KIND, 0, true, 0, true>(a, s) : v2_launch1<L, KIND, 0, false, 0, true>(a, s);
+            else return a.win ? v2_launch1<L, KIND, 0, true, MODE, true>(a, s) : v2_launch1<L, KIND, 0, false, MODE, true>(a, s);
         }
     }
     if constexpr (MODE == 1) {
@@ -487,11 +510,16 @@ template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hi
         return v2_launch1<L, KIND, 0, true, 1>(a, s);
     } else {
         const bool win = a.win != nullptr;
-        if (a.hop == N / 2) return win ? v2_launch1<L, KIND, E / 2, true, 0>(a, s) : v2_launch1<L, KIND, E / 2, false, 0>(a, s);
-        if constexpr (WIDE) {
-            if (a.hop == N / 4) return win ? v2_launch1<L, KIND, E / 4, true, 0>(a, s) : v2_launch1<L, KIND, E / 4, false, 0>(a, s);
+        if constexpr (MODE == 2) {  // the redraw path: the reference's hop == nfft and 50 % overlap, no window
+            if (a.hop == N / 2 && !win) return v2_launch1<L, KIND, E / 2, false, 2>(a, s);
+            return win ? v2_launch1<L, KIND, 0, true, 2>(a, s) : v2_launch1<L, KIND, 0, false, 2>(a, s);
+        } else {
+            if (a.hop == N / 2) return win ? v2_launch1<L, KIND, E / 2, true, 0>(a, s) : v2_launch1<L, KIND, E / 2, false, 0>(a, s);
+            if constexpr (WIDE) {
+                if (a.hop == N / 4) return win ? v2_launch1<L, KIND, E / 4, true, 0>(a, s) : v2_launch1<L, KIND, E / 4, false, 0>(a, s);
+            }
+            return win ? v2_launch1<L, KIND, 0, true, 0>(a, s) : v2_launch1<L, KIND, 0, false, 0>(a, s);
         }
-        return win ? v2_launch1<L, KIND, 0, true, 0>(a, s) : v2_launch1<L, KIND, 0, false, 0>(a, s);
     }
 }
 
@@ -512,8 +540,8 @@ template <int MODE> hipError_t v2_launch_n(const V2Args &a, int log2n, int kind,
     case 10: return v2_launch_kind<10, MODE>(a, kind, s);
     case 11: return v2_launch_kind<11, MODE>(a, kind, s);
     case 12: return v2_launch_kind<12, MODE>(a, kind, s);
-    case 13: return v2_launch_kind<13, MODE>(a, kind, s);
-    case 14: return v2_launch_kind<14, MODE>(a, kind, s);
+    case 13: if constexpr (MODE != 2) return v2_launch_kind<13, MODE>(a, kind, s); else return hipErrorInvalidValue;
+    case 14: if constexpr (MODE != 2) return v2_launch_kind<14, MODE>(a, kind, s); else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
 }

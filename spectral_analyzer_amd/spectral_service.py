@@ -197,8 +197,18 @@ class SpectralService:
                          max_db: float = 0.0, colormap: int = L.CMAP_GRAYSCALE) -> np.ndarray:
         """One redraw of ``MainController.updateDisplay()`` (MC:962-1049): ``width`` lines from
         ``start_byte`` rendered to a BGRA8 image; the dB tile stays on the device."""
-        b = _host_bytes(buffer)
         hop = int(nfft if hop is None else hop)
+        if _is_torch(buffer):  # device-resident recording -> device-resident image
+            import torch
+            if not buffer.is_cuda or buffer.dtype != torch.uint8 or not buffer.is_contiguous():
+                raise ValueError("device buffer must be a contiguous CUDA uint8 tensor")
+            img = torch.empty((int(height), int(width), 4), dtype=torch.uint8, device=buffer.device)
+            self._check(self._lib.spec_waterfall_render(
+                self._ctx, buffer.data_ptr(), 1, buffer.numel(), int(start_byte), dtype_from_sigmf(datatype), int(nfft),
+                hop, int(width), window, int(height), float(fs), float(min_db), float(max_db), colormap,
+                img.data_ptr(), 1))
+            return img
+        b = _host_bytes(buffer)
         out = np.empty((int(height), int(width), 4), dtype=np.uint8)
         self._check(self._lib.spec_waterfall_render(
             self._ctx, b.ctypes.data, 0, b.size, int(start_byte), dtype_from_sigmf(datatype), int(nfft), hop,

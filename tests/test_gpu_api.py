@@ -464,3 +464,41 @@ def test_compute_magnitudes_readahead_is_transparent(svc, oracle, datatype, nfft
             svc.compute_magnitudes(iq, (last + 1) * nfft * bps, nfft, datatype)
     finally:
         svc.set_option("readahead_lines", 256)
+
+
+# ---- fused render: only the bins the image samples leave the FFT kernel -------------------------------
+@pytest.mark.parametrize("datatype,nfft,hop,height", [("cf32_le", 4096, 4096, 600), ("cf32_le", 4096, 2048, 4096),
+                                                       ("ci16_le", 1024, 1024, 333), ("cu8", 256, 256, 256),
+                                                       ("ci16_be", 2048, 1024, 1000), ("ci8", 512, 300, 17)])
+@pytest.mark.parametrize("colormap", [sa.CMAP_GRAYSCALE, sa.CMAP_HEATMAP])
+def test_waterfall_render_fused_equals_two_pass(svc, oracle, datatype, nfft, hop, height, colormap):
+    """spec_waterfall_render with the compact tile (default) must give the very pixels of the two-pass form
+    (full dB tile, then the colour kernel), EOF columns included, and both match the restated Java renderer
+    applied to the GPU's own dB tile."""
+    width = 150
+    n = (width - 4) * hop + nfft                      # the last three columns run past the end: -150 dB
+    iq = oracle.synth_iq(datatype, 13, 0, n)
+    fs, lo, hi = 2.0e6, -120.0, -20.0
+    fused = svc.waterfall_render(iq, 0, nfft, datatype, width, height, fs, min_db=lo, max_db=hi, colormap=colormap, hop=hop)
+    svc.set_option("render_fused", 0)
+    try:
+        plain = svc.waterfall_render(iq, 0, nfft, datatype, width, height, fs, min_db=lo, max_db=hi, colormap=colormap, hop=hop)
+    finally:
+        svc.set_option("render_fused", 1)
+    assert fused.shape == (height, width, 4) and np.array_equal(fused, plain)
+    tile = svc.compute_waterfall(iq, 0, nfft, datatype, width, hop=hop)
+    assert np.array_equal(fused, oracle.render_spectrogram(tile.astype(np.float64), height, fs, lo, hi, colormap))
+
+
+def test_waterfall_render_fused_device_resident(svc, oracle):
+    import torch
+    nfft, width, height = 4096, 512, 700
+    iq = svc.synth_iq("cf32_le", 21, 0, width * nfft)
+    img = svc.waterfall_render(iq, 0, nfft, "cf32_le", width, height, 1e6)
+    svc.set_option("render_fused", 0)
+    try:
+        ref = svc.waterfall_render(iq, 0, nfft, "cf32_le", width, height, 1e6)
+    finally:
+        svc.set_option("render_fused", 1)
+    torch.cuda.synchronize()
+    assert img.is_cuda and torch.equal(img, ref)
