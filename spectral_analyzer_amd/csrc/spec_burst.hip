@@ -78,22 +78,41 @@ __global__ __launch_bounds__(256) void boxcar_decim_kernel(const uint8_t *__rest
     }
 }
 
-// y[m] = sum_k h[k] xm[m down + c - k], zero outside [0, n)
+// y[m] = sum_k h[k] xm[m down + c - k], zero outside [0, n).  G adjacent lanes share one output: lane g takes
+// the taps g, g + G, g + 2G, ... so the group reads G consecutive samples per step (one thread per output
+// would read with a stride of `down` doubles per lane), then log2(G) butterfly steps add the partial sums.
+// A tree, not the tap-order loop of the definition: equal to it to rounding (|dy| <= 1e-12 max|x| in the
+// tests, measured ~1e-16).
+template <int G>
 __global__ __launch_bounds__(256) void fir_decim_kernel(const double *__restrict__ mr, const double *__restrict__ mi,
                                                         uint64_t n, const double *__restrict__ h, uint32_t K,
                                                         uint32_t c, uint32_t down, double *__restrict__ ore,
                                                         double *__restrict__ oim, uint64_t n_out) {
-    for (uint64_t m = (uint64_t)blockIdx.x * 256 + threadIdx.x; m < n_out; m += (uint64_t)gridDim.x * 256) {
-        const int64_t top = (int64_t)(m * down) + (int64_t)c;  // index read by tap 0
+    constexpr int PER_WG = 256 / G;  // outputs per workgroup and step
+    const int g = threadIdx.x % G, sub = threadIdx.x / G;
+    for (uint64_t m0 = (uint64_t)blockIdx.x * PER_WG; m0 < n_out; m0 += (uint64_t)gridDim.x * PER_WG) {
+        const uint64_t m = m0 + sub;
         double ar = 0.0, ai = 0.0;
-        for (uint32_t k = 0; k < K; ++k) {
-            const int64_t idx = top - (int64_t)k;
-            if (idx < 0 || (uint64_t)idx >= n) continue;
-            ar += h[k] * mr[idx];
-            ai += h[k] * mi[idx];
+        if (m < n_out) {
+            const int64_t top = (int64_t)(m * down) + (int64_t)c;  // index read by tap 0
+            for (uint32_t k = g; k < K; k += G) {
+                const int64_t idx = top - (int64_t)k;
+                if (idx >= 0 && (uint64_t)idx < n) {
+                    const double hk = h[k];
+                    ar += hk * mr[idx];
+                    ai += hk * mi[idx];
+                }
+            }
         }
-        ore[m] = ar;
-        oim[m] = ai;
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            ar += __shfl_xor(ar, off, 64);
+            ai += __shfl_xor(ai, off, 64);
+        }
+        if (g == 0 && m < n_out) {
+            ore[m] = ar;
+            oim[m] = ai;
+        }
     }
 }
 
@@ -224,9 +243,17 @@ hipError_t launch_boxcar_decim(const uint8_t *raw, int kind, int be, uint32_t st
 hipError_t launch_fir_decim(const double *mr, const double *mi, uint64_t n, const double *h, uint32_t K, uint32_t c,
                             uint32_t down, double *ore, double *oim, uint64_t n_out, hipStream_t s) {
     if (n_out == 0) return hipSuccess;
-    const uint64_t wgs = (n_out + 255) / 256;
-    hipLaunchKernelGGL(fir_decim_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(256), 0, s, mr, mi, n, h, K, c,
-                       down, ore, oim, n_out);
+    // lanes per output: about one lane per eight taps, a power of two between 1 and 64
+    int G = 1;
+    while (G < 64 && (uint32_t)(G * 16) <= K) G *= 2;
+    const uint64_t per_wg = 256 / G, wgs64 = (n_out + per_wg - 1) / per_wg;
+    const dim3 grid((unsigned)(wgs64 < 32768 ? wgs64 : 32768)), block(256);
+#define SPEC_FIR_CASE(GG) case GG: hipLaunchKernelGGL(fir_decim_kernel<GG>, grid, block, 0, s, mr, mi, n, h, K, c, down, ore, oim, n_out); break
+    switch (G) {
+        SPEC_FIR_CASE(1); SPEC_FIR_CASE(2); SPEC_FIR_CASE(4); SPEC_FIR_CASE(8);
+        SPEC_FIR_CASE(16); SPEC_FIR_CASE(32); SPEC_FIR_CASE(64);
+    }
+#undef SPEC_FIR_CASE
     return hipGetLastError();
 }
 
