@@ -65,3 +65,49 @@ def test_random_requests_match_oracle(svc, oracle, seed):
                     check_fp32(got[:n_lines], ref, max(nfft, 4))
             except AssertionError as e:
                 raise AssertionError("%s: %s" % (tag, e))
+
+
+def _burst_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        dt = str(rng.choice(DTYPES))
+        count = int(rng.choice([1, 2, 63, 64, 65, 1000, 4097, int(rng.integers(1, 60000))]))
+        start = int(rng.integers(0, 100))
+        down = int(rng.choice([1, 2, 3, 7, 8, 16, 33, 100, 257]))
+        fast = bool(rng.integers(0, 2))
+        f_off = float(rng.choice([0.0, 0.25, -0.4999, 1e-7, float(rng.uniform(-0.5, 0.5))]))
+        alpha = float(rng.choice([0.0, 1.0, 0.001, float(rng.uniform(0, 1))]))
+        on_device = bool(rng.integers(0, 2))
+        yield dt, start, count, down, fast, f_off, alpha, on_device, int(rng.integers(1, 1 << 30))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_burst_requests_match_oracle(svc, oracle, seed):
+    """The burst chain (EDC:54-117, ADC:219-284) end to end on random requests: reader bit-exact, down-converter
+    and traces within the fp64 tolerances of tests/test_gpu_burst.py, host and device residency."""
+    import torch
+    edc = sa.ExtractDownConvertService(svc)
+    for dt, start, count, down, fast, f_off, alpha, on_device, s in _burst_cases(seed, 40):
+        tag = (dt, start, count, down, fast, f_off, alpha, on_device)
+        iq = oracle.synth_iq(dt, s, 0, start + count + 5)
+        buf = torch.from_numpy(iq).cuda() if on_device else iq
+        to_np = (lambda x: x.cpu().numpy()) if on_device else (lambda x: x)
+        re, im = oracle.extract_iq(iq, start, count, dt)
+        got = to_np(edc.extract_iq(buf, start, count, dt))
+        assert np.array_equal(got[0], re) and np.array_equal(got[1], im), tag
+        rr, ri = oracle.down_convert(re, im, f_off, down, 0 if fast else 1)
+        d = edc.extract_and_down_convert(buf, start, count, dt, f_off, down, fast)
+        dn = to_np(d)
+        assert dn.shape == (2, count // down), tag
+        if count // down == 0:
+            continue
+        m = max(np.abs(re).max(), np.abs(im).max(), 1e-30)
+        assert np.abs(dn[0] - rr).max() <= 1e-12 * m and np.abs(dn[1] - ri).max() <= 1e-12 * m, tag
+        fs = 1e6 / down
+        mag, frq = to_np(svc.magnitude_trace(d, alpha)), to_np(svc.inst_freq_trace(d, alpha, fs, 1e9))
+        ref_mag = oracle.magnitude_trace(dn[0], dn[1], alpha)
+        v = 10 ** (ref_mag / 20)
+        ok = np.isfinite(ref_mag) & (v >= 1e-9 * v[np.isfinite(v)].max()) if np.isfinite(v).any() else np.zeros(len(v), bool)
+        assert np.abs(mag[ok] - ref_mag[ok]).max(initial=0.0) <= 1e-9, tag
+        ref_frq = oracle.inst_freq_trace(dn[0], dn[1], alpha, fs, 1e9)
+        assert frq.shape == ref_frq.shape and np.abs(frq - ref_frq).max(initial=0.0) <= 1e-9 * fs + 1e-6, tag
