@@ -505,7 +505,7 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
     std::deque<OutJob> jobs;
     bool closing = false, slot_busy[2] = {false, false};
     hipError_t worker_err = hipSuccess;
-    const bool threaded = !out_on_device && n_chunks > 1;
+    bool threaded = !out_on_device && n_chunks > 1;
     uint8_t *const h_out = static_cast<uint8_t *>(out);
     auto copy_out = [&](const OutJob &j) -> hipError_t {  // device -> host of one finished chunk
         hipError_t e = hipStreamWaitEvent(c->s_out, c->ev_done[j.slot], 0);
@@ -516,8 +516,7 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
         return e;
     };
     std::thread worker;
-    if (threaded)
-        worker = std::thread([&] {
+    auto worker_main = [&] {
             (void)hipSetDevice(c->device);
             for (;;) {
                 OutJob j;
@@ -536,7 +535,11 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
                 }
                 cv.notify_all();
             }
-        });
+        };
+    if (threaded) {
+        try { worker = std::thread(worker_main); }
+        catch (...) { threaded = false; }  // no thread to be had: copy out from this thread, without the overlap
+    }
     spec_status pst = SPEC_OK;
     hipError_t perr = hipSuccess;
     uint64_t chunk = 0;
@@ -884,7 +887,8 @@ spec_status spec_waterfall_render(spec_ctx *c, const void *iq, int iq_on_device,
         height <= nfft && dtype_valid(dt) && hop >= 1 && fs > 0 &&
         (colormap == SPEC_CMAP_GRAYSCALE || colormap == SPEC_CMAP_HEATMAP) &&
         v2_sel_applicable(ilog2(nfft), kind_of(dt, c->flags), is_be(dt), n_lines, hop)) {
-        std::vector<int32_t> sel(nfft, -1);
+        std::vector<int32_t> sel;
+        try { sel.assign(nfft, -1); } catch (...) { return fail(c, SPEC_ENOMEM, "out of host memory"); }
         bool one_to_one = true;
         for (uint32_t f = 0; f < height && one_to_one; ++f) {
             const int bin = (int)((double)f / (double)height * (double)nfft);  // MC:1280, fftshifted index
@@ -1036,7 +1040,8 @@ spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_dev
     } else {
         // taps of the stated specification (include/specgpu.h), fp64 on the host
         const uint32_t K = 8 * down + 1, centre = 4 * down;
-        std::vector<double> h(K);
+        std::vector<double> h;
+        try { h.resize(K); } catch (...) { return fail(c, SPEC_ENOMEM, "out of host memory for %u filter taps", K); }
         double sum = 0.0;
         for (uint32_t k = 0; k < K; ++k) {
             const double x = ((double)k - 4.0 * down) / (double)down;
