@@ -13,6 +13,8 @@
 // fastest gets coalesced runs, the other side gets the FFT's own stride-T order.
 // Scratch is sized per chunk of lines (<= 256 MiB) so that it lives in the
 // 256 MiB Infinity Cache between the two kernels.
+#include <type_traits>
+
 #include "spec_kernels.h"
 
 namespace specgpu {
@@ -43,8 +45,16 @@ struct LargeArgs {
     int out_fmt;
 };
 
-template <typename R, int L1, int L2>
-__global__ __launch_bounds__(Plan<L1>::WG) void large_cols_kernel(const LargeArgs a) {
+// Both kernels walk TPW consecutive tiles per workgroup and request the next tile's operands before the
+// FFT of the current one (the same software prefetch as the LDS-resident family): with 70 KiB of LDS per
+// workgroup only two workgroups share a CU, too few to hide the load latency by occupancy alone.
+constexpr uint32_t LARGE_TPW = 4;  // row kernel: consecutive tiles per workgroup
+constexpr uint32_t LARGE_LPW = 8;  // column kernel: consecutive lines (of one column tile) per workgroup
+
+// DIRECT: the samples already are cx<R> in memory (little-endian cf64 for double, cf32 for float), so a load
+// needs no decode and can stay in flight behind the current tile's FFT
+template <typename R, int L1, int L2, bool DIRECT>
+__global__ __launch_bounds__(Plan<L1>::WG, 2) void large_cols_kernel(const LargeArgs a) {
     using LG = Large<R, L1, L2>;
     using PA = typename LG::PA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -52,79 +62,136 @@ __global__ __launch_bounds__(Plan<L1>::WG) void large_cols_kernel(const LargeArg
     const int tid = threadIdx.x;
     const int q0 = tid % LG::CA, t0 = tid / LG::CA;  // loads: columns fastest (contiguous samples)
     const int t1 = tid % PA::T, q1 = tid / PA::T;    // stores: k1 fastest (contiguous scratch)
-    constexpr int TILES = LG::N2 / LG::CA;
-    const uint32_t line = blockIdx.x / TILES, c0 = (blockIdx.x % TILES) * LG::CA;
-    const uint8_t *src = a.iq + (uint64_t)line * a.hop * a.bps;
+    constexpr uint32_t TILES = LG::N2 / LG::CA;
+    // a workgroup walks LARGE_LPW consecutive LINES of one column tile: at 50 % overlap line l+1's rows
+    // n1 < N1/2 are line l's rows n1 + N1/2, i.e. this thread's registers m + E/2 -- half of every tile
+    // after the first is a register move instead of a load
+    const uint32_t c0 = (blockIdx.x % TILES) * LG::CA;
+    const uint32_t l0 = (blockIdx.x / TILES) * LARGE_LPW, l1 = l0 + LARGE_LPW < a.n_lines ? l0 + LARGE_LPW : a.n_lines;
+    const bool half = (uint64_t)a.hop * 2 == (uint64_t)LG::N;  // uniform
     const R *__restrict__ win = static_cast<const R *>(a.win);
 
     // sub-FFT twiddles W_N1 into LDS
     cx<R> *tab = lds + (size_t)LG::CA * LG::SA;
     for (int e = tid; e < PA::N; e += PA::WG) tab[e] = static_cast<const cx<R> *>(a.tw1)[e];
 
-    cx<R> v[PA::E];
+    auto load_rows = [&](uint32_t line, cx<R> (&x)[PA::E], auto first_tag) {  // rows m >= FIRST of a line's tile
+        constexpr int FIRST = decltype(first_tag)::value;
+        const uint8_t *src = a.iq + (uint64_t)line * a.hop * a.bps;
 #pragma unroll
-    for (int m = 0; m < PA::E; ++m) {
-        const uint32_t n = (uint32_t)(t0 + m * PA::T) * LG::N2 + c0 + q0;
-        v[m] = decode_sample<R>(src + (uint64_t)n * a.bps, a.kind, a.be != 0);
-        if (win) { const R w = win[n]; v[m].x *= w; v[m].y *= w; }
-    }
+        for (int m = FIRST; m < PA::E; ++m) {
+            const uint32_t n = (uint32_t)(t0 + m * PA::T) * LG::N2 + c0 + q0;
+            if constexpr (DIRECT) x[m] = *reinterpret_cast<const cx<R> *>(src + (uint64_t)n * sizeof(cx<R>));
+            else x[m] = decode_sample<R>(src + (uint64_t)n * a.bps, a.kind, a.be != 0);
+        }
+    };
+    cx<R> nxt[PA::E];
+    load_rows(l0, nxt, std::integral_constant<int, 0>{});
     __syncthreads();  // table visible
-    fft_line_remap<R, L1>(v, t0, lds + (size_t)q0 * LG::SA, t1, lds + (size_t)q1 * LG::SA, tab);
-    // inter-step twiddle W_N^(n2 k1), k1 = t1 + m T: W^(n2 t1) * (W^(n2 T))^m by recurrence in
-    // fp64 (two table reads per thread instead of sixteen scattered ones; 15 roundings of 1e-16)
     const cx<double> *__restrict__ twn = static_cast<const cx<double> *>(a.twn);
-    const uint32_t n2 = c0 + q1;
-    cx<double> w = twn[n2 * (uint32_t)t1];
-    const cx<double> step = twn[n2 * (uint32_t)PA::T];
-    cx<R> *dst = static_cast<cx<R> *>(a.scratch) + (uint64_t)line * LG::N + (uint64_t)n2 * LG::N1;
+    for (uint32_t line = l0; line < l1; ++line) {
+        cx<R> v[PA::E];
 #pragma unroll
-    for (int m = 0; m < PA::E; ++m) {
-        const cx<double> z = cmul(cx<double>{(double)v[m].x, (double)v[m].y}, w);
-        dst[t1 + m * PA::T] = cx<R>{(R)z.x, (R)z.y};
-        w = cmul(w, step);
+        for (int m = 0; m < PA::E; ++m) v[m] = nxt[m];
+        if (line + 1 < l1) {
+            if (half) {
+#pragma unroll
+                for (int m = 0; m < PA::E / 2; ++m) nxt[m] = nxt[m + PA::E / 2];
+                load_rows(line + 1, nxt, std::integral_constant<int, PA::E / 2>{});
+            } else {
+                load_rows(line + 1, nxt, std::integral_constant<int, 0>{});
+            }
+        }
+        if (win) {
+#pragma unroll
+            for (int m = 0; m < PA::E; ++m) {
+                const R w = win[(uint32_t)(t0 + m * PA::T) * LG::N2 + c0 + q0];
+                v[m].x *= w;
+                v[m].y *= w;
+            }
+        }
+        fft_line_remap<R, L1>(v, t0, lds + (size_t)q0 * LG::SA, t1, lds + (size_t)q1 * LG::SA, tab);
+        // inter-step twiddle W_N^(n2 k1), k1 = t1 + m T: W^(n2 t1) * (W^(n2 T))^m by recurrence in
+        // fp64 (two table reads per thread instead of sixteen scattered ones; 15 roundings of 1e-16)
+        const uint32_t n2 = c0 + q1;
+        cx<double> w = twn[n2 * (uint32_t)t1];
+        const cx<double> step = twn[n2 * (uint32_t)PA::T];
+        cx<R> *dst = static_cast<cx<R> *>(a.scratch) + (uint64_t)line * LG::N + (uint64_t)n2 * LG::N1;
+#pragma unroll
+        for (int m = 0; m < PA::E; ++m) {
+            const cx<double> z = cmul(cx<double>{(double)v[m].x, (double)v[m].y}, w);
+            dst[t1 + m * PA::T] = cx<R>{(R)z.x, (R)z.y};
+            w = cmul(w, step);
+        }
     }
 }
 
+// two workgroups (LDS) of four waves per CU = 2 waves per SIMD: keep the allocation within 256 registers
 template <typename R, int L1, int L2>
-__global__ __launch_bounds__(Plan<L2>::WG) void large_rows_kernel(const LargeArgs a) {
+__global__ __launch_bounds__(Plan<L2>::WG, 2) void large_rows_kernel(const LargeArgs a) {
     using LG = Large<R, L1, L2>;
     using PB = typename LG::PB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cx<R> *lds = reinterpret_cast<cx<R> *>(smem);
     const int tid = threadIdx.x;
     const int q0 = tid % LG::CB, t0 = tid / LG::CB;  // rows k1 fastest: both the scratch reads and the final stores
-    constexpr int TILES = LG::N1 / LG::CB;
-    const uint32_t line = blockIdx.x / TILES, r0 = (blockIdx.x % TILES) * LG::CB;
-    const cx<R> *src = static_cast<const cx<R> *>(a.scratch) + (uint64_t)line * LG::N + r0 + q0;
+    constexpr uint32_t TILES = LG::N1 / LG::CB;
+    const uint32_t total = a.n_lines * TILES;
+    const uint32_t g0 = blockIdx.x * LARGE_TPW, g1 = g0 + LARGE_TPW < total ? g0 + LARGE_TPW : total;
 
     cx<R> *tab = lds + (size_t)LG::CB * LG::SB;
     for (int e = tid; e < PB::N; e += PB::WG) tab[e] = static_cast<const cx<R> *>(a.tw2)[e];
-    cx<R> v[PB::E];
+    auto load_tile = [&](uint32_t g, auto &x) {
+        const uint32_t line = g / TILES, r0 = (g % TILES) * LG::CB;
+        const cx<R> *src = static_cast<const cx<R> *>(a.scratch) + (uint64_t)line * LG::N + r0 + q0;
 #pragma unroll
-    for (int m = 0; m < PB::E; ++m) v[m] = src[(uint64_t)(t0 + m * PB::T) * LG::N1];  // [n2][k1]
+        for (int m = 0; m < PB::E; ++m) x[m] = src[(uint64_t)(t0 + m * PB::T) * LG::N1];  // [n2][k1]
+    };
+    // fp64: the dB epilogue already needs most of the 256 registers, a second tile in flight spills 65 of them;
+    // the tile loop alone (table set-up amortised) is kept
+    constexpr bool PREFETCH = sizeof(R) == 4;
+    cx<R> nxt[PREFETCH ? PB::E : 1];
+    (void)nxt;
+    if constexpr (PREFETCH) load_tile(g0, nxt);
     __syncthreads();  // table visible
-    // no role change is needed here (k1 stays the fast index), only the padded line stride
-    fft_line<R, L2>(v, t0, lds + (size_t)q0 * LG::SB, tab);
-    const uint64_t base = (uint64_t)line * LG::N;
+    for (uint32_t g = g0; g < g1; ++g) {
+        const uint32_t line = g / TILES, r0 = (g % TILES) * LG::CB;
+        cx<R> v[PB::E];
+        if constexpr (PREFETCH) {
 #pragma unroll
-    for (int m = 0; m < PB::E; ++m) {
-        const uint32_t k = (r0 + q0) + (uint32_t)LG::N1 * (t0 + m * PB::T);
-        store_bin<R>(a.out, base + ((k + LG::N / 2) & (LG::N - 1)), v[m], a.out_fmt);  // SS:78
+            for (int m = 0; m < PB::E; ++m) v[m] = nxt[m];
+            if (g + 1 < g1) load_tile(g + 1, nxt);
+        } else {
+            load_tile(g, v);
+        }
+        // no role change is needed here (k1 stays the fast index), only the padded line stride
+        fft_line<R, L2>(v, t0, lds + (size_t)q0 * LG::SB, tab);
+        const uint64_t base = (uint64_t)line * LG::N;
+#pragma unroll
+        for (int m = 0; m < PB::E; ++m) {
+            const uint32_t k = (r0 + q0) + (uint32_t)LG::N1 * (t0 + m * PB::T);
+            store_bin<R>(a.out, base + ((k + LG::N / 2) & (LG::N - 1)), v[m], a.out_fmt);  // SS:78
+        }
     }
 }
 
 template <typename R, int L1, int L2> hipError_t launch_large(const LargeArgs &a, hipStream_t s) {
     using LG = Large<R, L1, L2>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&large_cols_kernel<R, L1, L2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG::LDS_A);
+    // samples that already are cx<R> in memory need no decode
+    const bool direct = !a.be && a.kind == (sizeof(R) == 8 ? K_CF64 : K_CF32);
+    auto cols = direct ? &large_cols_kernel<R, L1, L2, true> : &large_cols_kernel<R, L1, L2, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cols), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LG::LDS_A);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&large_rows_kernel<R, L1, L2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG::LDS_B);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((large_cols_kernel<R, L1, L2>), dim3(a.n_lines * (LG::N2 / LG::CA)), dim3(LG::PA::WG), LG::LDS_A, s, a);
+    const uint32_t wgs_a = ((a.n_lines + LARGE_LPW - 1) / LARGE_LPW) * (LG::N2 / LG::CA), tiles_b = a.n_lines * (LG::N1 / LG::CB);
+    hipLaunchKernelGGL(cols, dim3(wgs_a), dim3(LG::PA::WG), LG::LDS_A, s, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((large_rows_kernel<R, L1, L2>), dim3(a.n_lines * (LG::N1 / LG::CB)), dim3(LG::PB::WG), LG::LDS_B, s, a);
+    hipLaunchKernelGGL((large_rows_kernel<R, L1, L2>), dim3((tiles_b + LARGE_TPW - 1) / LARGE_TPW), dim3(LG::PB::WG),
+                       LG::LDS_B, s, a);
     return hipGetLastError();
 }
 
