@@ -35,8 +35,14 @@ template <typename R> __device__ __forceinline__ void store_bin(void *out, uint6
 // SpectralService.java:33-85 (one line).  A workgroup owns `lines_per_wg`
 // consecutive lines and walks them LPW at a time, so overlapping spans
 // (hop < nfft) are re-read from this CU's L1 / the XCD's L2, not from HBM.
+// fp64: two workgroups per CU wherever the LDS allows it -- left alone the allocator takes 256 VGPRs plus
+// up to 112 AGPRs for the sixteen inlined dB epilogues and halves the residency
+template <typename R, int LOG2N> constexpr int spectro_min_waves() {
+    return sizeof(R) == 8 && Plan<LOG2N>::WG == 256 && (size_t)Plan<LOG2N>::LPW * Plan<LOG2N>::N * sizeof(cx<R>) <= 80 * 1024 ? 2 : 1;
+}
+
 template <typename R, int LOG2N>
-__global__ __launch_bounds__(Plan<LOG2N>::WG) void spectro_kernel(const WfArgs a) {
+__global__ __launch_bounds__(Plan<LOG2N>::WG, (spectro_min_waves<R, LOG2N>())) void spectro_kernel(const WfArgs a) {
     using PL = Plan<LOG2N>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, t = tid % PL::T, q = tid / PL::T;
@@ -68,8 +74,12 @@ __global__ __launch_bounds__(Plan<LOG2N>::WG) void spectro_kernel(const WfArgs a
         if (active) {
             const uint64_t base = line * (uint64_t)PL::N;
 #pragma unroll
-            for (int m = 0; m < PL::E; ++m)  // fftshift: (k + N/2) mod N   (SS:78)
+            for (int m = 0; m < PL::E; ++m) {  // fftshift: (k + N/2) mod N   (SS:78)
                 store_bin<R>(a.out, base + (uint64_t)((t + m * PL::T + PL::N / 2) & (PL::N - 1)), v[m], a.out_fmt);
+                // fp64: finish one bin's sqrt / log series before starting the next (the scheduler would
+                // interleave all sixteen and need their temporaries at once)
+                if constexpr (sizeof(R) == 8) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
