@@ -214,12 +214,13 @@ spec_status spec_welch_psd(spec_ctx *ctx, const void *iq, int iq_on_device, uint
 
 /* The same estimate for the exact argument shape of the reference call
  *   PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft)
- * (AnalysisDialogController.java:308-312): planar doubles data[0] = I, data[1] = Q, host
- * memory, as produced by ExtractDownConvertService.  Every whole segment of the signal is used
+ * (AnalysisDialogController.java:308-312): planar doubles data[0] = I, data[1] = Q as produced by
+ * ExtractDownConvertService -- in host memory, or (in_on_device != 0) still on the device where
+ * spec_down_convert left them.  Every whole segment of the signal is used
  * (n_seg = (n_samples - nfft)/hop + 1); fp64 pipeline.  freq_out / psd_out: nfft values, host. */
-spec_status spec_welch_psd_planar_f64(spec_ctx *ctx, const double *re, const double *im, uint64_t n_samples,
-                                      uint32_t nfft, uint32_t hop, spec_window window, spec_psd_scaling scaling,
-                                      double fs, int db, double *freq_out, float *psd_out);
+spec_status spec_welch_psd_planar_f64(spec_ctx *ctx, const double *re, const double *im, int in_on_device,
+                                      uint64_t n_samples, uint32_t nfft, uint32_t hop, spec_window window,
+                                      spec_psd_scaling scaling, double fs, int db, double *freq_out, float *psd_out);
 
 /* ---- burst analysis (the Analysis dialog) ---------- */
 

@@ -47,7 +47,7 @@ public:
                                                        uint32_t nfft) const {
         std::vector<double> f(nfft);
         std::vector<float> p(nfft);
-        check(spec_welch_psd_planar_f64(ctx_, re, im, n, nfft, nfft / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY, fs, 0,
+        check(spec_welch_psd_planar_f64(ctx_, re, im, 0, n, nfft, nfft / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY, fs, 0,
                                         f.data(), p.data()), ctx_);
         return {f, std::vector<double>(p.begin(), p.end())};
     }

@@ -138,7 +138,7 @@ JNIEXPORT void JNICALL JNI_FN(nativeWelchPlanar)(JNIEnv *env, jclass k, jlong h,
     jdouble *i = (*env)->GetDoubleArrayElements(env, im, NULL);
     jdouble *f = (*env)->GetDoubleArrayElements(env, freq, NULL);
     jfloat *p = (*env)->GetFloatArrayElements(env, psd, NULL);
-    spec_status st = spec_welch_psd_planar_f64(ctx, r, i, (uint64_t)n, (uint32_t)nfft, (uint32_t)hop,
+    spec_status st = spec_welch_psd_planar_f64(ctx, r, i, 0, (uint64_t)n, (uint32_t)nfft, (uint32_t)hop,
                                                (spec_window)window, (spec_psd_scaling)scaling, fs, db ? 1 : 0, f, p);
     (*env)->ReleaseFloatArrayElements(env, psd, p, st == SPEC_OK ? 0 : JNI_ABORT);
     (*env)->ReleaseDoubleArrayElements(env, freq, f, st == SPEC_OK ? 0 : JNI_ABORT);

@@ -47,7 +47,7 @@ SIGNATURES = {
     "spec_render_spectrogram": (_i32, [_vp, _vp, _i32, _u32, _u32, _u32, _dbl, _dbl, _dbl, _i32, _vp, _i32]),
     "spec_waterfall_render": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u32, _i32, _u32, _dbl, _dbl,
                                      _dbl, _i32, _vp, _i32]),
-    "spec_welch_psd_planar_f64": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "spec_welch_psd_planar_f64": (_i32, [_vp, _vp, _vp, _i32, _u64, _u32, _u32, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "spec_extract_iq": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _i32, _vp, _vp, _i32]),
     "spec_down_convert": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _i32, _dbl, _u32, _i32, _vp, _vp, _i32]),
     "spec_magnitude_trace": (_i32, [_vp, _vp, _vp, _i32, _u64, _dbl, _vp, _i32]),

@@ -70,6 +70,7 @@ hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int
 // compact != 0: tile is [width][height] with column f = the bin pixel row f samples (launch_v2_spectro_sel)
 hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
                          double min_db, double max_db, int colormap, int compact, void *bgra, hipStream_t s);
+hipError_t launch_interleave(const double *re, const double *im, void *out, uint64_t n, hipStream_t s);
 hipError_t launch_synth(void *out, int kind, int be, uint64_t seed, uint64_t first_sample,
                         uint64_t n_samples, hipStream_t s);
 

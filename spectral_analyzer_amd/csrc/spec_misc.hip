@@ -122,6 +122,21 @@ __global__ void render_kernel(const float *__restrict__ tile, uint32_t width, ui
     out[(uint64_t)y * width + x] = make_uchar4(ch(b), ch(g), ch(r), 255);         // BGRA
 }
 
+// planar doubles (the reference's double[2][N], ADC:216,298) -> interleaved cf64
+__global__ void interleave_kernel(const double *__restrict__ re, const double *__restrict__ im,
+                                  double2 *__restrict__ out, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = make_double2(re[i], im[i]);
+}
+
+hipError_t launch_interleave(const double *re, const double *im, void *out, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const uint64_t wgs = (n + 255) / 256;
+    hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)(wgs < 65536 ? wgs : 65536)), dim3(256), 0, s, re, im,
+                       static_cast<double2 *>(out), n);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
                          double min_db, double max_db, int colormap, int compact, void *bgra, hipStream_t s) {
     if (width == 0 || height == 0) return hipSuccess;

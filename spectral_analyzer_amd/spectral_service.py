@@ -261,15 +261,14 @@ class SpectralService:
         ``data`` is ``double[2][N]`` (row 0 = I, row 1 = Q); returns ``[freq, psd]`` like the
         reference's two rows.  Window / overlap / scaling are explicit because JDSP's are not
         known (defaults: Hann, 50 %, density, linear)."""
-        d = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
-        if d.ndim != 2 or d.shape[0] != 2:
-            raise ValueError("data must be double[2][N]")
+        keep, pre, pim, n, dev = self._planar(data)  # host double[2][N] or a device tensor (the down-converter's)
         hop = int(nfft // 2 if hop is None else hop)
         freq = np.empty(max(int(nfft), 0), dtype=np.float64)
         psd = np.empty(max(int(nfft), 0), dtype=np.float32)
         self._check(self._lib.spec_welch_psd_planar_f64(
-            self._ctx, d[0].ctypes.data, d[1].ctypes.data, d.shape[1], int(nfft) & 0xFFFFFFFF, hop, window,
+            self._ctx, pre, pim, dev, n, int(nfft) & 0xFFFFFFFF, hop, window,
             scaling, float(fs), int(db), freq.ctypes.data, psd.ctypes.data))
+        del keep
         return np.stack([freq, psd.astype(np.float64)])
 
     # -- Analysis dialog traces (ADC:219-284) --------------------------------

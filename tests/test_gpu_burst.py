@@ -129,3 +129,18 @@ def test_burst_fixtures(svc, edc):
         check_mag(svc.magnitude_trace(data, float(g["alpha"])), g["mag"])
         assert np.abs(svc.inst_freq_trace(data, float(g["alpha"]), float(g["fs"]), float(g["center"])) - g["freq"]).max() \
             <= 1e-9 * float(g["fs"])
+
+
+def test_psd_of_a_device_resident_burst(svc, edc, oracle):
+    """The PSD dialog's call (ADC:308-312) on the down-converter's output without leaving the GPU equals the
+    same call on a host copy, and the build-defined Welch of the oracle."""
+    n, down = 1 << 18, 4
+    iq = svc.synth_iq("cf32_le", 17, 0, n)
+    d = edc.extract_and_down_convert(iq, 0, n, "cf32_le", 0.11, down, False)
+    on_dev = svc.calculate_psd_welch(d, 2.5e5, 8192)
+    host = d.cpu().numpy()
+    on_host = svc.calculate_psd_welch(host, 2.5e5, 8192)
+    assert np.array_equal(on_dev, on_host)
+    raw = np.empty(2 * host.shape[1]); raw[0::2], raw[1::2] = host[0], host[1]
+    f, p = oracle.welch_psd(raw.view(np.uint8), 0, "cf64_le", 8192, 4096, (host.shape[1] - 8192) // 4096 + 1, fs=2.5e5)
+    assert np.allclose(on_dev[0], f) and np.abs(on_dev[1] - p).max() <= 2e-6 * p.max()
