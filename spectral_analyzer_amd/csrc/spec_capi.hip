@@ -359,6 +359,25 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     const int lpw = plan_lpw(log2n);
     const bool v2 = !f64 && !c->opt_force_generic &&
                     v2_applicable(log2n, a.kind, a.be, a.out_fmt, n_lines, hop);
+    if (f64 && !d_sel && !c->opt_force_generic && a.kind != K_ZERO && v3d_applicable(log2n, a.kind, n_lines, hop)) {
+        // fp64 member of the packed family (strict-parity pipeline), same launch geometry as below
+        const uint64_t sub = (uint64_t)v2_lpw(log2n);
+        uint64_t done = 0;
+        while (done < n_lines) {
+            const uint64_t rem = n_lines - done;
+            uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg
+                                                    : (rem + sub * c->n_cu * 8 - 1) / (sub * c->n_cu * 8);
+            if (run < 1) run = 1;
+            if (run > 32) run = 32;
+            a.n_lines = rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_v3d_spectro(a, log2n, (uint32_t)run, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "fp64 spectrogram launch: %s", hipGetErrorString(e));
+            done += a.n_lines;
+        }
+        return SPEC_OK;
+    }
     if (v2) {
         // packed-fp32 family: every sub-line (T threads) walks its own run of consecutive lines
         const uint64_t sub = (uint64_t)v2_lpw(log2n);

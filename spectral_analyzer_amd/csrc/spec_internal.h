@@ -55,6 +55,9 @@ hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void
 bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, uint32_t hop);
 int v2_lpw(int log2n);  // sub-lines per workgroup
 hipError_t launch_v2_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream_t s);
+// fp64 member of the family (spec_v3d.h): 256 ... 4096 points, any sample format, fp64 arithmetic
+bool v3d_applicable(int log2n, int kind, uint64_t n_lines, uint32_t hop);
+hipError_t launch_v3d_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream_t s);
 bool v2_sel_applicable(int log2n, int kind, int be, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v2_spectro_sel(const WfArgs &w, int log2n, uint32_t run, const int32_t *sel, uint32_t out_stride,
                                  hipStream_t s);

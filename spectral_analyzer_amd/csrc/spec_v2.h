@@ -61,8 +61,8 @@ template <int L> constexpr int p2_tab_off_of(int pass) {
 }
 template <int L, int PASS> constexpr int p2_tab_off() { return p2_tab_off_of<L>(PASS); }
 template <int L> constexpr int p2_tab_entries() { return p2_tab_off_of<L>(Plan2<L>::NPASS - 1); }
-template <int L> constexpr size_t p2_lds_bytes() {
-    return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * 8 + (size_t)p2_tab_entries<L>() * 8;
+template <int L, int ELEM = 8> constexpr size_t p2_lds_bytes() {  // ELEM: bytes per complex value (8 fp32, 16 fp64)
+    return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * ELEM + (size_t)p2_tab_entries<L>() * ELEM;
 }
 
 // ---- raw sample formats (SS:40-59); SCALE is folded into the epilogue -------------
@@ -74,8 +74,27 @@ template <> struct Raw2<K_CF32> {
     template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
         return __builtin_amdgcn_raw_buffer_load_b64(r, v, s, AUX);
     }
-    static __device__ __forceinline__ v2f dec(type u) { return v2f{__uint_as_float(u.x), __uint_as_float(u.y)}; }
+    template <typename V = v2f> static __device__ __forceinline__ V dec(type u) {
+        return pk_make<V>(__uint_as_float(u.x), __uint_as_float(u.y));
+    }
     static __device__ __forceinline__ type swap(type u) { return type{__builtin_bswap32(u.x), __builtin_bswap32(u.y)}; }
+};
+// cf64 (EDC:79-81): fp64 family only
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <> struct Raw2<K_CF64> {
+    using type = u32x4;
+    static constexpr int BPS = 16;
+    static constexpr float SCALE = 1.0f;
+    template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, v, s, AUX);
+    }
+    template <typename V = v2d> static __device__ __forceinline__ V dec(type u) {
+        return pk_make<V>(__longlong_as_double((long long)(((uint64_t)u.y << 32) | u.x)),
+                          __longlong_as_double((long long)(((uint64_t)u.w << 32) | u.z)));
+    }
+    static __device__ __forceinline__ type swap(type u) {  // reverse the eight bytes of each double
+        return type{__builtin_bswap32(u.y), __builtin_bswap32(u.x), __builtin_bswap32(u.w), __builtin_bswap32(u.z)};
+    }
 };
 template <> struct Raw2<K_CI16> {
     using type = uint32_t;
@@ -84,8 +103,9 @@ template <> struct Raw2<K_CI16> {
     template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
         return __builtin_amdgcn_raw_buffer_load_b32(r, v, s, AUX);
     }
-    static __device__ __forceinline__ v2f dec(type u) {
-        return v2f{(float)(int16_t)(u & 0xFFFFu), (float)((int32_t)u >> 16)};
+    template <typename V = v2f> static __device__ __forceinline__ V dec(type u) {
+        using S = pk_scalar_t<V>;
+        return V{(S)(int16_t)(u & 0xFFFFu), (S)((int32_t)u >> 16)};
     }
     // big-endian file: swap the two bytes of each 16-bit component
     static __device__ __forceinline__ type swap(type u) { return ((u & 0x00FF00FFu) << 8) | ((u >> 8) & 0x00FF00FFu); }
@@ -97,7 +117,10 @@ template <> struct Raw2<K_CI8> {
     template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
         return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, v, s, AUX);
     }
-    static __device__ __forceinline__ v2f dec(type u) { return v2f{(float)(int8_t)(u & 0xFF), (float)(int8_t)(u >> 8)}; }
+    template <typename V = v2f> static __device__ __forceinline__ V dec(type u) {
+        using S = pk_scalar_t<V>;
+        return V{(S)(int8_t)(u & 0xFF), (S)(int8_t)(u >> 8)};
+    }
     static __device__ __forceinline__ type swap(type u) { return u; }
 };
 template <> struct Raw2<K_CU8> {
@@ -107,8 +130,9 @@ template <> struct Raw2<K_CU8> {
     template <int AUX> static __device__ __forceinline__ type load(__amdgpu_buffer_rsrc_t r, int v, int s) {
         return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, v, s, AUX);
     }
-    static __device__ __forceinline__ v2f dec(type u) {
-        return v2f{(float)(u & 0xFF), (float)(u >> 8)} - v2f{127.5f, 127.5f};
+    template <typename V = v2f> static __device__ __forceinline__ V dec(type u) {
+        using S = pk_scalar_t<V>;
+        return V{(S)(u & 0xFF), (S)(u >> 8)} - pk_make<V>(127.5, 127.5);
     }
     static __device__ __forceinline__ type swap(type u) { return u; }
 };
@@ -126,24 +150,24 @@ template <int SHIFT> __device__ __forceinline__ int padn_rt(int a) { return a + 
 // table `tab` (entry (r, k) at r*P + k); the last pass from
 // the per-thread registers `twl` (W_N^(r t); the second butterfly of an E = 32
 // thread sits T = N/32 further on: one more factor W_32^r, a compile-time constant).
-template <int L, int PASS>
-__device__ __forceinline__ void v2_pass(v2f (&v)[Plan2<L>::E], int t, const v2f *tab, v2f (&twl)[16]) {
+template <int L, int PASS, typename V>
+__device__ __forceinline__ void v2_pass(V (&v)[Plan2<L>::E], int t, const V *tab, V (&twl)[16]) {
     using PL = Plan2<L>;
     constexpr int E = PL::E, R = PL::radix[PASS], S = E / R, P = p2_P<L, PASS>();
     if constexpr (PASS > 0 && PASS < PL::NPASS - 1) {
         // k = (t + s T) mod P is the same for every s (P divides T): one table row for all butterflies
         static_assert(S == 1 || PL::T % P == 0, "butterflies of a thread share their twiddles");
-        const v2f *row = tab + p2_tab_off<L, PASS>() + (t & (P - 1));
+        const V *row = tab + p2_tab_off<L, PASS>() + (t & (P - 1));
 #pragma unroll
         for (int r = 1; r < R; ++r) {
-            const v2f q = row[r * P];
+            const V q = row[r * P];
 #pragma unroll
             for (int s = 0; s < S; ++s) v[s + r * S] = pk_cmul(v[s + r * S], q);
         }
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        v2f u[R];
+        V u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = v[s + r * S];
         if constexpr (PASS == PL::NPASS - 1) {
@@ -162,32 +186,32 @@ __device__ __forceinline__ void v2_pass(v2f (&v)[Plan2<L>::E], int t, const v2f 
 
 // registers -> LDS after PASS.  Index of output r of butterfly i = t + s T:
 //   hi*(R P) + r P + k,  k = i mod P, hi = i / P      (Stockham autosort)
-template <int L, int PASS> __device__ __forceinline__ void v2_store(const v2f (&v)[Plan2<L>::E], int t, v2f *lds) {
+template <int L, int PASS, typename V> __device__ __forceinline__ void v2_store(const V (&v)[Plan2<L>::E], int t, V *lds) {
     using PL = Plan2<L>;
     constexpr int R = PL::radix[PASS], S = PL::E / R, P = p2_P<L, PASS>(), SH = PL::PADSH;
     if constexpr (P >= 16) {  // wide stride: plain layout is conflict free
         static_assert(S == 1 || PL::T % P == 0, "butterfly s sits s*T*R elements further on");
-        v2f *base = lds + ((t & ~(P - 1)) * R + (t & (P - 1)));
+        V *base = lds + ((t & ~(P - 1)) * R + (t & (P - 1)));
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int r = 0; r < R; ++r) base[s * PL::T * R + r * P] = v[s + r * S];
     } else if constexpr (PASS == 0) {  // P == 1: a = i R + r, padded: pad(t R) + s*pad(T R) + r
         static_assert((PL::T * R) % (1 << SH) == 0 && R <= (1 << SH), "sub-line stride must be a multiple of the pad period");
-        v2f *base = lds + padn_rt<SH>(t * R);
+        V *base = lds + padn_rt<SH>(t * R);
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int r = 0; r < R; ++r) base[padn<SH>(s * PL::T * R) + r] = v[s + r * S];
     } else {  // 1 < P < 16, R = 16, S = 1: hi*(17 P) + k + pad(r P)
         static_assert(S == 1 && R == 16 && SH == 4, "middle passes are single radix-16 butterflies");
-        v2f *base = lds + ((t / P) * (17 * P) + (t & (P - 1)));
+        V *base = lds + ((t / P) * (17 * P) + (t & (P - 1)));
 #pragma unroll
         for (int r = 0; r < R; ++r) base[padn<4>(r * P)] = v[r];
     }
 }
 // LDS -> registers at stride T after the exchange written by PASS
-template <int L, int PASS> __device__ __forceinline__ void v2_load(v2f (&v)[Plan2<L>::E], int t, const v2f *lds) {
+template <int L, int PASS, typename V> __device__ __forceinline__ void v2_load(V (&v)[Plan2<L>::E], int t, const V *lds) {
     using PL = Plan2<L>;
     constexpr int SH = PL::PADSH;
     if constexpr (p2_P<L, PASS>() >= 16) {
@@ -195,19 +219,19 @@ template <int L, int PASS> __device__ __forceinline__ void v2_load(v2f (&v)[Plan
         for (int m = 0; m < PL::E; ++m) v[m] = lds[t + m * PL::T];
     } else {
         static_assert(PL::T < (1 << SH) || PL::T % (1 << SH) == 0, "pad(t + m T) = pad(t) + pad(m T)");
-        const v2f *base = lds + (PL::T >= (1 << SH) ? padn_rt<SH>(t) : t);
+        const V *base = lds + (PL::T >= (1 << SH) ? padn_rt<SH>(t) : t);
 #pragma unroll
         for (int m = 0; m < PL::E; ++m) v[m] = base[padn<SH>(m * PL::T)];
     }
 }
 
 // W_N^(r k STEP) for the (r, k) of one middle pass
-template <int L, int PASS> __device__ __forceinline__ void fill_tables(v2f *tab, const v2f *__restrict__ tw, int tid) {
+template <int L, int PASS, typename V> __device__ __forceinline__ void fill_tables(V *tab, const V *__restrict__ tw, int tid) {
     using PL = Plan2<L>;
     if constexpr (PASS < PL::NPASS - 1) {
         constexpr int P = p2_P<L, PASS>(), R = PL::radix[PASS], STEP = PL::N / (P * R);
         for (int e = tid; e < R * P; e += PL::WG) {
-            const v2f w0 = tw[(e / P) * (e % P) * STEP];
+            const V w0 = tw[(e / P) * (e % P) * STEP];
             tab[p2_tab_off<L, PASS>() + e] = w0;
         }
         fill_tables<L, PASS + 1>(tab, tw, tid);
@@ -226,8 +250,8 @@ template <int L> __device__ __forceinline__ void v2_sync() {
     }
 }
 
-template <int L, int PASS = 0>
-__device__ __forceinline__ void v2_fft(v2f (&v)[Plan2<L>::E], int t, v2f *lds, const v2f *tab, v2f (&twl)[16]) {
+template <int L, int PASS = 0, typename V>
+__device__ __forceinline__ void v2_fft(V (&v)[Plan2<L>::E], int t, V *lds, const V *tab, V (&twl)[16]) {
     using PL = Plan2<L>;
     // SPEC_ABL_*: ablation builds of tools/ablate.sh (one stage removed, results wrong by construction,
     // DESIGN.md 4.7); never defined in a product build

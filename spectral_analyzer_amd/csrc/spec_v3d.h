@@ -1,0 +1,149 @@
+// spec_v3d.h -- the fp64 member of the packed kernel family: the strict-parity pipeline (cf64 recordings and
+// the SPEC_OUT_*_F64 outputs, |dB error| <= 1e-9) with the structure of spec_v2.h -- small radix first, LDS
+// twiddle tables for the middle pass, last-pass twiddles in registers, padded LDS exchanges, one run of
+// consecutive lines per sub-line with the next line's samples in flight behind the current FFT, overlap
+// reuse in registers, buffer addressing.  Arithmetic is scalar fp64 on 2-vectors (spec_fft_pk.h, V = v2d).
+// 256 ... 4096 points (16 points per thread: 64 VGPRs of line state); longer fp64 lines stay on the generic
+// and four-step kernels.
+#pragma once
+#include "spec_v2.h"
+
+namespace specgpu {
+
+namespace {
+
+// spectrogram lines (MC:980-999 around SS:33-85), fp64 arithmetic; OUT64: doubles out, else floats
+template <int L, int KIND, int SH, bool HAS_WIN, bool BE>
+__global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
+    using PL = Plan2<L>;
+    using RW = Raw2<KIND>;
+    using raw_t = typename RW::type;
+    static_assert(PL::E == 16, "fp64 family: 16 points per thread");
+    constexpr int BPS = RW::BPS, N = PL::N, T = PL::T, E = PL::E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, t = tid % T, q = tid / T;
+    v2d *lds = reinterpret_cast<v2d *>(smem) + (size_t)q * PL::LINE;
+    v2d *tab = reinterpret_cast<v2d *>(smem + (size_t)PL::LPW * PL::LINE * 16);
+    const v2d *__restrict__ tw = static_cast<const v2d *>(a.tw);
+
+    if constexpr (PL::NPASS > 2) fill_tables<L, 1>(tab, tw, tid);
+    v2d twl[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    const double *win = static_cast<const double *>(a.win);
+    if constexpr (PL::NPASS > 2) __syncthreads();
+
+    const uint32_t wg = blockIdx.x;
+    const uint32_t line0 = wg * (uint32_t)PL::LPW * a.run;
+    uint32_t lines_wg = a.n_lines - line0;
+    if (lines_wg > (uint32_t)PL::LPW * a.run) lines_wg = PL::LPW * a.run;
+    const uint32_t line_bytes = a.hop * BPS;
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.iq) + (uint64_t)line0 * line_bytes, 0, (lines_wg - 1) * line_bytes + (uint32_t)N * BPS, 0x00020000);
+    const int voff = (int)(q * a.run * line_bytes) + t * BPS;
+    constexpr int AUX = 2, ST_AUX = 2;
+    constexpr int NEW = SH > 0 ? SH : E;
+    // The next line's samples stay in flight behind the current FFT only for the 2- and 4-byte formats
+    // (16 / 16 registers).  For cf32 / cf64 the 32 / 64 registers of a second line push the kernel over its
+    // 256 and the spills cost more than the prefetch hides (measured: cf64 4096-pt 37 -> 46 M lines/s,
+    // cf32 -> f64 51 -> 53 M lines/s without it); those load each line at its start.
+    constexpr bool PREFETCH = KIND != K_CF64 && KIND != K_CF32;
+    raw_t raw[E];
+    if constexpr (PREFETCH) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, m * T * BPS);
+    }
+
+    const bool out64 = a.out_fmt == OUT_DB20_F64 || a.out_fmt == OUT_POW_F64;
+    const bool out_db = a.out_fmt == OUT_DB20_F64 || a.out_fmt == OUT_DB20_F32;
+    const uint32_t esz = out64 ? 8u : 4u;
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<uint8_t *>(a.out) + (uint64_t)line0 * N * esz, 0, lines_wg * (uint32_t)N * esz, 0x00020000);
+    const int ovoff = (int)(q * a.run * (uint32_t)N * esz) + t * (int)esz;
+    const uint32_t my_first = q * a.run;
+    const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
+    const uint32_t iters = PL::WAVE_LOCAL ? a.run : my_lines;
+    constexpr double scale = (double)RW::SCALE;
+
+    for (uint32_t line = 0; line < iters; ++line) {
+        v2d v[E];
+        if constexpr (!PREFETCH) {
+            const int off = (int)(line * line_bytes);
+#pragma unroll
+            for (int m = 0; m < E; ++m) raw[m] = RW::template load<0>(src, voff, off + m * T * BPS);
+        }
+#pragma unroll
+        for (int m = 0; m < E; ++m) v[m] = RW::template dec<v2d>(BE ? RW::swap(raw[m]) : raw[m]);  // SMH:87-91
+        if constexpr (HAS_WIN) {
+            const double *wp = win;
+            asm volatile("" : "+s"(wp));  // window values are re-read every line (no registers to keep them)
+#pragma unroll
+            for (int m = 0; m < E; ++m) { const double w = wp[t + m * T]; v[m] *= v2d{w, w}; }
+        }
+        if constexpr (PREFETCH) {
+            if constexpr (SH > 0 && SH < E) {
+#pragma unroll
+                for (int m = 0; m < E - SH; ++m) raw[m] = raw[m + SH];
+            }
+            const int next_off = (int)((line + 1) * line_bytes);
+#pragma unroll
+            for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
+        }
+
+        v2_fft<L>(v, t, lds, tab, twl);
+
+        // out[(k + N/2) mod N] = 20 log10(|X_k| + 1e-10)  (SS:78-81), or |X_k|^2
+        const int out_off = (int)(line * (uint32_t)N * esz);
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const double val = out_db ? db20(cx<double>{v[m].x * scale, v[m].y * scale}) : pk_norm(v[m]) * (scale * scale);
+            const int so = out_off + ((m + E / 2) & (E - 1)) * T * (int)esz;
+            if (out64) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)bits, (uint32_t)(bits >> 32)}, dst, ovoff, so, ST_AUX);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)val), dst, ovoff, so, ST_AUX);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one bin's sqrt / log series at a time
+        }
+    }
+}
+
+template <int L, int KIND, int SH, bool HAS_WIN, bool BE = false>
+hipError_t v3d_launch1(const V2Args &a, hipStream_t s) {
+    using PL = Plan2<L>;
+    constexpr size_t lds = p2_lds_bytes<L, 16>();
+    auto kern = v3d_kernel<L, KIND, SH, HAS_WIN, BE>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.wgs_per_unit), dim3(PL::WG), lds, s, a);
+    return hipGetLastError();
+}
+
+// register-reuse variant for 50 % overlap; every other hop and big-endian files re-read the overlap from L2
+template <int L, int KIND> hipError_t v3d_launch_sh(const V2Args &a, hipStream_t s) {
+    constexpr int N = Plan2<L>::N, E = Plan2<L>::E;
+    const bool win = a.win != nullptr;
+    if constexpr (KIND == K_CF32 || KIND == K_CI16 || KIND == K_CF64) {
+        if (a.be) return win ? v3d_launch1<L, KIND, 0, true, true>(a, s) : v3d_launch1<L, KIND, 0, false, true>(a, s);
+    }
+    if (a.hop == N / 2) return win ? v3d_launch1<L, KIND, E / 2, true>(a, s) : v3d_launch1<L, KIND, E / 2, false>(a, s);
+    return win ? v3d_launch1<L, KIND, 0, true>(a, s) : v3d_launch1<L, KIND, 0, false>(a, s);
+}
+
+template <int L> hipError_t v3d_launch_kind(const V2Args &a, int kind, hipStream_t s) {
+    switch (kind) {
+    case K_CF64: return v3d_launch_sh<L, K_CF64>(a, s);
+    case K_CF32: return v3d_launch_sh<L, K_CF32>(a, s);
+    case K_CI16: return v3d_launch_sh<L, K_CI16>(a, s);
+    case K_CU8: return v3d_launch_sh<L, K_CU8>(a, s);
+    case K_CI8: return v3d_launch_sh<L, K_CI8>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+}  // namespace specgpu
