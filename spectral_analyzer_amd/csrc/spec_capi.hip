@@ -361,7 +361,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                     v2_applicable(log2n, a.kind, a.be, a.out_fmt, n_lines, hop);
     if (f64 && !d_sel && !c->opt_force_generic && a.kind != K_ZERO && v3d_applicable(log2n, a.kind, n_lines, hop)) {
         // fp64 member of the packed family (strict-parity pipeline), same launch geometry as below
-        const uint64_t sub = (uint64_t)v2_lpw(log2n);
+        const uint64_t sub = log2n == 13 ? 1 : (uint64_t)v2_lpw(log2n);  // fp64 8192 points: one line per workgroup
         uint64_t done = 0;
         while (done < n_lines) {
             const uint64_t rem = n_lines - done;

@@ -44,6 +44,17 @@ SPEC_PLAN2(12, 16, 3, 16, 16, 16, 1)
 SPEC_PLAN2(13, 32, 3, 32, 16, 16, 1)
 SPEC_PLAN2(14, 32, 3, 32, 32, 16, 1)
 #undef SPEC_PLAN2
+// Plan id 113: 8192 points with 16-point threads (2 x 16 x 16 x 16, 512 threads per line), used by the fp64
+// member of the family only (spec_v3d.h): a 32-point fp64 thread would need 128 registers for its line alone.
+// The id stands where log2(nfft) stands in every template of this file; nothing derives N from it.
+template <> struct Plan2<113> {
+    static constexpr int E = 16, N = 8192, T = N / E, NPASS = 4;
+    static constexpr int radix[4] = {2, 16, 16, 16};
+    static constexpr int WG = T, LPW = 1;
+    static constexpr bool WAVE_LOCAL = false;
+    static constexpr int PADSH = 4;
+    static constexpr int LINE = N + (N >> PADSH);
+};
 
 template <int L> constexpr int p2_P_of(int pass) {  // product of the radices before `pass`
     int p = 1;

@@ -3,8 +3,8 @@
 // twiddle tables for the middle pass, last-pass twiddles in registers, padded LDS exchanges, one run of
 // consecutive lines per sub-line with the next line's samples in flight behind the current FFT, overlap
 // reuse in registers, buffer addressing.  Arithmetic is scalar fp64 on 2-vectors (spec_fft_pk.h, V = v2d).
-// 256 ... 4096 points (16 points per thread: 64 VGPRs of line state); longer fp64 lines stay on the generic
-// and four-step kernels.
+// 256 ... 8192 points (16 points per thread: 64 VGPRs of line state; 8192 = plan id 113 of spec_v2.h); longer
+// fp64 lines stay on the generic and four-step kernels.
 #pragma once
 #include "spec_v2.h"
 
