@@ -366,7 +366,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 #pragma unroll
         for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
     }
-    if constexpr (PL::NPASS > 2) __syncthreads();
+    // (the barrier that publishes the tables comes after the first line's loads have been issued)
 
     // ---- this workgroup's span: LPW consecutive runs of `run` lines of one unit
     const uint32_t unit = blockIdx.x / a.wgs_per_unit, wg = blockIdx.x % a.wgs_per_unit;
@@ -420,6 +420,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     const uint32_t my_first = q * a.run;
     const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
     const uint32_t iters = PL::WAVE_LOCAL ? a.run : my_lines;  // whole-workgroup lines: LPW == 1
+
+    if constexpr (PL::NPASS > 2) __syncthreads();  // LDS twiddle tables visible
 
     // 50 % overlap, cf32 spectrogram: the two register halves swap roles from one line to the next
     // (two copies of the loop body) instead of being moved; every other variant shifts the
