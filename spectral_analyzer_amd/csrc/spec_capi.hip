@@ -369,6 +369,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                                                     : (rem + sub * c->n_cu * 8 - 1) / (sub * c->n_cu * 8);
             if (run < 1) run = 1;
             if (run > 32) run = 32;
+            while (run > 1 && sub * run * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;
             a.n_lines = rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull;
             a.iq = d_first + done * (uint64_t)hop * a.bps;
             a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
@@ -388,6 +389,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                                                     : (rem + sub * c->n_cu * 8 - 1) / (sub * c->n_cu * 8);
             if (run < 1) run = 1;
             if (run > 32) run = 32;
+            // 32-bit byte offsets inside a workgroup's span (input and output side)
+            while (run > 1 && sub * run * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;
             const uint64_t max_lines = 0x7FFFFFFFull;  // 32-bit line index inside one launch
             a.n_lines = rem < max_lines ? rem : max_lines;
             a.iq = d_first + done * (uint64_t)hop * a.bps;
