@@ -88,3 +88,41 @@ def test_4096_hops_windows(svc, oracle, datatype, window, hop):
     finally:
         svc.set_option("force_generic", 0)
     check_fp32(got_g, ref, nfft)
+
+
+# ---- 32-point-per-thread plans (8192 = 32x16x16, 16384 = 32x32x16): every overlap / window / format variant ----
+@pytest.mark.parametrize("nfft", [8192, 16384])
+@pytest.mark.parametrize("hop_div", [1, 2, 4, 3])          # hop = nfft, nfft/2 (shift E/2), nfft/4 (shift E/4), odd hop
+@pytest.mark.parametrize("datatype,window", [("cf32_le", sa.WIN_RECT), ("cf32_le", sa.WIN_HANN), ("ci16_le", sa.WIN_RECT),
+                                             ("ci16_be", sa.WIN_HANN), ("cu8", sa.WIN_RECT), ("ci8", sa.WIN_HANN),
+                                             ("cf32_be", sa.WIN_RECT)])
+def test_long_lines_all_variants(svc, oracle, nfft, hop_div, datatype, window):
+    hop = nfft // hop_div if hop_div != 3 else nfft // 3 + 5
+    n_lines = 7
+    iq = oracle.synth_iq(datatype, seed=nfft // 64 + hop_div, first_sample=11, n_samples=(n_lines - 1) * hop + nfft)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines + 1, window)
+    got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + 1, hop=hop, window=window)
+    assert np.all(got[-1] == -150.0)
+    check_fp32(got[:-1], ref[:-1], nfft)
+
+
+# ---- fp64 member of the family: every size, format, overlap, window, output format -------------------------------
+@pytest.mark.parametrize("nfft", [256, 512, 1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("datatype,hop_div,window", [("cf64_le", 2, sa.WIN_RECT), ("cf64_be", 1, sa.WIN_HANN),
+                                                     ("cf32_le", 2, sa.WIN_HANN), ("cf32_be", 4, sa.WIN_RECT),
+                                                     ("ci16_le", 2, sa.WIN_RECT), ("ci16_be", 3, sa.WIN_HANN),
+                                                     ("cu8", 2, sa.WIN_HANN), ("ci8", 1, sa.WIN_RECT)])
+def test_fp64_family_all_variants(svc, oracle, nfft, datatype, hop_div, window):
+    hop = nfft // hop_div if hop_div != 3 else nfft // 3 + 1
+    n_lines = 11
+    iq = oracle.synth_iq(datatype, seed=nfft // 8 + hop_div, first_sample=3, n_samples=(n_lines - 1) * hop + nfft)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines + 1, window)
+    got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + 1, hop=hop, window=window, out_fmt=sa.OUT_DB20_F64)
+    assert got.dtype == np.float64 and np.all(got[-1] == -150.0)
+    check_fp64(got[:-1], ref[:-1])
+    pw = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_POW_F64)
+    ref_pw = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window, power=True)
+    assert np.abs(pw - ref_pw).max() <= 1e-12 * ref_pw.max()
+    if datatype.startswith("cf64"):   # fp64 arithmetic, fp32 storage
+        f32 = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_DB20_F32)
+        assert f32.dtype == np.float32 and np.abs(f32 - got[:-1]).max() <= 2e-5
