@@ -116,6 +116,57 @@ __global__ __launch_bounds__(256) void fir_decim_kernel(const double *__restrict
     }
 }
 
+// Conventional mode in one pass: a workgroup decodes and mixes the span its outputs need straight into LDS
+// (planar, 16 KiB + 16 KiB for 2048 samples) and runs the grouped FIR from there -- no scratch round trip of the
+// mixed burst.  Spans of neighbouring workgroups overlap by K - down samples (3 % at down = 8).
+constexpr int FIR_SPAN = 2048;  // samples of the mixed burst held per workgroup
+
+template <int G>
+__global__ __launch_bounds__(256) void mix_fir_kernel(const uint8_t *__restrict__ raw, int kind, int be, uint32_t stride,
+                                                      uint64_t n, double freq_off, const double *__restrict__ h,
+                                                      uint32_t K, uint32_t c, uint32_t down, uint32_t outs_wg,
+                                                      double *__restrict__ ore, double *__restrict__ oim,
+                                                      uint64_t n_out) {
+    __shared__ double lre[FIR_SPAN], lim[FIR_SPAN];
+    constexpr int PER_STEP = 256 / G;
+    const int g = threadIdx.x % G, sub = threadIdx.x / G;
+    for (uint64_t m0 = (uint64_t)blockIdx.x * outs_wg; m0 < n_out; m0 += (uint64_t)gridDim.x * outs_wg) {
+        const uint32_t outs = n_out - m0 < outs_wg ? (uint32_t)(n_out - m0) : outs_wg;
+        const uint32_t span = (outs - 1) * down + K;
+        const int64_t first = (int64_t)(m0 * down) + (int64_t)c - (int64_t)(K - 1);  // burst index of lre[0]
+        __syncthreads();  // the previous tile has been read
+        for (uint32_t i = threadIdx.x; i < span; i += 256) {
+            const int64_t idx = first + i;
+            cx<double> z{0.0, 0.0};
+            if (idx >= 0 && (uint64_t)idx < n) z = read_mixed(raw, kind, be, stride, (uint64_t)idx, freq_off);
+            lre[i] = z.x;
+            lim[i] = z.y;
+        }
+        __syncthreads();
+        for (uint32_t o0 = 0; o0 < outs; o0 += PER_STEP) {
+            const uint32_t o = o0 + sub;
+            double ar = 0.0, ai = 0.0;
+            if (o < outs) {
+                const uint32_t top = o * down + (K - 1);  // span index read by tap 0
+                for (uint32_t k = g; k < K; k += G) {
+                    const double hk = h[k];
+                    ar += hk * lre[top - k];
+                    ai += hk * lim[top - k];
+                }
+            }
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) {
+                ar += __shfl_xor(ar, off, 64);
+                ai += __shfl_xor(ai, off, 64);
+            }
+            if (g == 0 && o < outs) {
+                ore[m0 + o] = ar;
+                oim[m0 + o] = ai;
+            }
+        }
+    }
+}
+
 // ---- traces -------------------------------------------------------------------------------------
 struct Aff { double a, b; };  // v -> a v + b
 __device__ __forceinline__ Aff then(Aff first, Aff second) { return {first.a * second.a, second.a * first.b + second.b}; }
@@ -254,6 +305,29 @@ hipError_t launch_fir_decim(const double *mr, const double *mi, uint64_t n, cons
         SPEC_FIR_CASE(16); SPEC_FIR_CASE(32); SPEC_FIR_CASE(64);
     }
 #undef SPEC_FIR_CASE
+    return hipGetLastError();
+}
+
+// one-pass conventional down-converter; false when the filter does not fit the LDS span (very large `down`)
+bool mix_fir_applicable(uint32_t K, uint32_t down) { return (uint64_t)K + down <= FIR_SPAN; }
+
+hipError_t launch_mix_fir(const uint8_t *raw, int kind, int be, uint32_t stride, uint64_t n, double freq_off,
+                          const double *h, uint32_t K, uint32_t c, uint32_t down, double *ore, double *oim, uint64_t n_out,
+                          hipStream_t s) {
+    if (n_out == 0) return hipSuccess;
+    int G = 1;
+    while (G < 64 && (uint32_t)(G * 16) <= K) G *= 2;
+    uint32_t outs_wg = (FIR_SPAN - K) / down + 1;  // (outs - 1) down + K <= FIR_SPAN
+    const uint32_t per_step = 256 / G;
+    if (outs_wg > per_step) outs_wg -= outs_wg % per_step;  // whole steps
+    const uint64_t wgs64 = (n_out + outs_wg - 1) / outs_wg;
+    const dim3 grid((unsigned)(wgs64 < 32768 ? wgs64 : 32768)), block(256);
+#define SPEC_MF_CASE(GG) case GG: hipLaunchKernelGGL(mix_fir_kernel<GG>, grid, block, 0, s, raw, kind, be, stride, n, freq_off, h, K, c, down, outs_wg, ore, oim, n_out); break
+    switch (G) {
+        SPEC_MF_CASE(1); SPEC_MF_CASE(2); SPEC_MF_CASE(4); SPEC_MF_CASE(8);
+        SPEC_MF_CASE(16); SPEC_MF_CASE(32); SPEC_MF_CASE(64);
+    }
+#undef SPEC_MF_CASE
     return hipGetLastError();
 }
 

@@ -1088,15 +1088,26 @@ spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_dev
             sum += h[k];
         }
         for (uint32_t k = 0; k < K; ++k) h[k] /= sum;
-        // scratch: mixed samples (planar) + taps
-        spec_status st = grow(c, &c->scratch, &c->scratch_bytes, (2 * count + K) * sizeof(double));
+        const bool one_pass = mix_fir_applicable(K, down);  // the span of a workgroup's outputs fits the LDS
+        // scratch: taps (+ the mixed samples, planar, when the filter is too long for the one-pass kernel)
+        spec_status st = grow(c, &c->scratch, &c->scratch_bytes, ((one_pass ? 0 : 2 * count) + K) * sizeof(double));
         if (st != SPEC_OK) return st;
-        double *d_mr = static_cast<double *>(c->scratch), *d_mi = d_mr + count, *d_h = d_mi + count;
+        double *d_h = static_cast<double *>(c->scratch), *d_mr = d_h + K, *d_mi = d_mr + count;
         HIP_TRY(c, hipMemcpyAsync(d_h, h.data(), K * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        st = burst_read(c, buffer, buffer_on_device, capacity, start_sample, count, dt, freq_off, d_mr, d_mi);
-        if (st == SPEC_OK) {
-            hipError_t e = launch_fir_decim(d_mr, d_mi, count, d_h, K, centre, down, d_or, d_oi, n_out, c->stream);
-            if (e != hipSuccess) st = fail(c, SPEC_EDEVICE, "filter launch: %s", hipGetErrorString(e));
+        if (one_pass) {
+            const uint8_t *d_raw; int kind; uint32_t stride;
+            st = burst_locate(c, buffer, buffer_on_device, capacity, start_sample, count, dt, &d_raw, &kind, &stride);
+            if (st == SPEC_OK) {
+                hipError_t e = launch_mix_fir(d_raw, kind, is_be(dt), stride, count, freq_off, d_h, K, centre, down, d_or, d_oi,
+                                              n_out, c->stream);
+                if (e != hipSuccess) st = fail(c, SPEC_EDEVICE, "filter launch: %s", hipGetErrorString(e));
+            }
+        } else {
+            st = burst_read(c, buffer, buffer_on_device, capacity, start_sample, count, dt, freq_off, d_mr, d_mi);
+            if (st == SPEC_OK) {
+                hipError_t e = launch_fir_decim(d_mr, d_mi, count, d_h, K, centre, down, d_or, d_oi, n_out, c->stream);
+                if (e != hipSuccess) st = fail(c, SPEC_EDEVICE, "filter launch: %s", hipGetErrorString(e));
+            }
         }
         (void)hipStreamSynchronize(c->stream);  // `h` (pageable host memory) must outlive its copy
         if (st != SPEC_OK) return st;

@@ -84,6 +84,10 @@ hipError_t launch_boxcar_decim(const uint8_t *raw, int kind, int be, uint32_t st
                                double *ore, double *oim, uint64_t n_out, hipStream_t s);
 hipError_t launch_fir_decim(const double *mr, const double *mi, uint64_t n, const double *h, uint32_t K, uint32_t c,
                             uint32_t down, double *ore, double *oim, uint64_t n_out, hipStream_t s);
+bool mix_fir_applicable(uint32_t K, uint32_t down);
+hipError_t launch_mix_fir(const uint8_t *raw, int kind, int be, uint32_t stride, uint64_t n, double freq_off,
+                          const double *h, uint32_t K, uint32_t c, uint32_t down, double *ore, double *oim, uint64_t n_out,
+                          hipStream_t s);
 size_t trace_scratch_bytes(uint64_t n_out);
 // kind_trace 0: magnitude (n_out = n), 1: instantaneous frequency (n_out = n - 1)
 hipError_t launch_trace(int kind_trace, const double *re, const double *im, uint64_t n_out, double alpha, double fs,
