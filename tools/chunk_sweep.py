@@ -8,7 +8,7 @@ dt, nfft, hop, S = "cf64_le", 65536, 32768, 1 << 28
 n = (S - nfft) // hop + 1
 iq = svc.synth_iq(dt, 7, 0, S)
 out = torch.empty((n, nfft), dtype=torch.float64, device="cuda")
-for mb in (8, 16, 32, 64, 128, 192, 512):
+for mb in (16, 32, 64, 96, 128, 192, 256, 512, 1024, 4096):
     svc.set_option("large_chunk_mb", mb)
     ts = []
     for r in range(8):
