@@ -110,7 +110,7 @@ void *spec_stream(const spec_ctx *ctx);
 
 /* Tuning / testing knobs (not needed for normal use):
  *   "force_generic" = 1  route every request through the generic (scalar-math) kernels
- *   "lines_per_wg"  = n  consecutive lines walked by one sub-line / workgroup (0 = automatic)
+ *   "lines_per_wg"  = n  consecutive lines (Welch: segments) walked by one sub-line / workgroup (0 = automatic)
  *   "large_chunk_mb" = m scratch size of the four-step path (nfft >= 32768; default 1024 MiB)
  *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
  *   "render_fused" = 0 | 1   spec_waterfall_render stores only the bins the image samples (default 1; 0 = full

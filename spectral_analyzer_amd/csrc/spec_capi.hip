@@ -767,7 +767,8 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
         const uint32_t sub = (uint32_t)v2_lpw(log2n);
         // enough sub-lines to fill the chip first (a single 256-segment PSD gets one segment per
         // sub-line), long runs (register reuse, fewer slabs) once there is plenty of work
-        uint64_t run = ((uint64_t)n_seg * n_psd) / ((uint64_t)c->n_cu * 8 * sub);
+        uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg
+                                                : ((uint64_t)n_seg * n_psd) / ((uint64_t)c->n_cu * 8 * sub);
         if (run < 1) run = 1;
         if (run > 64) run = 64;
         if (run > n_seg) run = n_seg;
