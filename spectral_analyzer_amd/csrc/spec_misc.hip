@@ -87,19 +87,14 @@ hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int
 }
 
 // ---- renderSpectrogram + getColorForMagnitude (MC:1261-1291, MC:926-957): dB tile -> BGRA8 ----
-// One thread per pixel, x (time) fastest so the image stores coalesce.  The arithmetic follows the
-// Java expressions operation by operation (double for the bin / normalisation, float for
-// Color.interpolate, round-half-up to 8 bits); the _rn intrinsics keep hipcc from fusing them.
-__global__ void render_kernel(const float *__restrict__ tile, uint32_t width, uint32_t nfft, uint32_t height,
-                              double conversion, double min_db, double max_db, int colormap, int compact,
-                              uchar4 *__restrict__ out) {
-    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= width) return;
-    const uint32_t f = height - 1 - y;                                             // MC:1288
-    const int bin = (int)__dmul_rn(__ddiv_rn((double)f, (double)height), (double)nfft);  // MC:1280
-    // compact tile: the FFT kernel stored only the sampled bins, bin(f) at column f
-    const float tv = compact ? tile[(uint64_t)x * height + f] : tile[(uint64_t)x * nfft + bin];
-    const double db = __dsub_rn((double)tv, conversion);                                 // MC:1283
+// The tile is [x][bin] (one line per column x), the image [y][x]: a 32 x 32 block of pixels is read along
+// the bins (coalesced in the tile), coloured, turned in LDS and written along x (coalesced in the image) --
+// one thread per pixel in image order read the tile with a stride of a whole line per lane and ran at a
+// quarter of this rate.  The arithmetic follows the Java expressions operation by operation (double for
+// the bin / normalisation, float for Color.interpolate, round-half-up to 8 bits); the _rn intrinsics keep
+// hipcc from fusing them.
+__device__ __forceinline__ uint32_t render_pixel(float tv, double conversion, double min_db, double max_db, int colormap) {
+    const double db = __dsub_rn((double)tv, conversion);                           // MC:1283
     double n = __ddiv_rn(__dsub_rn(db, min_db), __dsub_rn(max_db, min_db));        // MC:929
     n = n < 0.0 ? 0.0 : (n > 1.0 ? 1.0 : n);                                       // MC:930
     float r, g, b;
@@ -118,8 +113,32 @@ __global__ void render_kernel(const float *__restrict__ tile, uint32_t width, ui
         r = n <= 0.0 ? 0.0f : (n >= 1.0 ? 1.0f : (float)n);
         g = b = r;
     }
-    auto ch = [](float c) { return (unsigned char)floor(__dadd_rn(__dmul_rn((double)c, 255.0), 0.5)); };
-    out[(uint64_t)y * width + x] = make_uchar4(ch(b), ch(g), ch(r), 255);         // BGRA
+    auto ch = [](float c) { return (uint32_t)(unsigned char)floor(__dadd_rn(__dmul_rn((double)c, 255.0), 0.5)); };
+    return ch(b) | (ch(g) << 8) | (ch(r) << 16) | 0xFF000000u;                     // B, G, R, A bytes
+}
+
+__global__ __launch_bounds__(256) void render_kernel(const float *__restrict__ tile, uint32_t width, uint32_t nfft,
+                                                     uint32_t height, double conversion, double min_db, double max_db,
+                                                     int colormap, int compact, uint32_t *__restrict__ out) {
+    __shared__ uint32_t px[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint32_t x0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // lanes along f: neighbouring bins of one line
+        const uint32_t x = x0 + ty + 8 * j, f = f0 + tx;
+        if (x < width && f < height) {
+            const int bin = (int)__dmul_rn(__ddiv_rn((double)f, (double)height), (double)nfft);  // MC:1280
+            // compact tile: the FFT kernel stored only the sampled bins, bin(f) at column f
+            const float tv = compact ? tile[(uint64_t)x * height + f] : tile[(uint64_t)x * nfft + bin];
+            px[ty + 8 * j][tx] = render_pixel(tv, conversion, min_db, max_db, colormap);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // lanes along x: neighbouring pixels of one image row
+        const uint32_t x = x0 + tx, f = f0 + ty + 8 * j;
+        if (x < width && f < height) out[(uint64_t)(height - 1 - f) * width + x] = px[tx][ty + 8 * j];  // MC:1288
+    }
 }
 
 // planar doubles (the reference's double[2][N], ADC:216,298) -> interleaved cf64
@@ -140,8 +159,8 @@ hipError_t launch_interleave(const double *re, const double *im, void *out, uint
 hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
                          double min_db, double max_db, int colormap, int compact, void *bgra, hipStream_t s) {
     if (width == 0 || height == 0) return hipSuccess;
-    hipLaunchKernelGGL(render_kernel, dim3((width + 255) / 256, height), dim3(256), 0, s, tile, width, nfft, height,
-                       conversion, min_db, max_db, colormap, compact, static_cast<uchar4 *>(bgra));
+    hipLaunchKernelGGL(render_kernel, dim3((width + 31) / 32, (height + 31) / 32), dim3(256), 0, s, tile, width, nfft, height,
+                       conversion, min_db, max_db, colormap, compact, static_cast<uint32_t *>(bgra));
     return hipGetLastError();
 }
 
