@@ -41,7 +41,9 @@ __device__ __forceinline__ cx<double> read_mixed(const uint8_t *__restrict__ raw
         double t = freq_off * (double)i;
         asm volatile("" : "+v"(t));
         t -= floor(t);
-        const double a = 2.0 * kPi * t, cs = cos(a), sn = sin(a);
+        const double a = 2.0 * kPi * t;
+        double sn, cs;
+        sincos(a, &sn, &cs);  // one argument reduction for both
         const double xr = x * cs + y * sn, xi = y * cs - x * sn;
         x = xr;
         y = xi;
