@@ -469,7 +469,10 @@ def test_compute_magnitudes_readahead_is_transparent(svc, oracle, datatype, nfft
 # ---- fused render: only the bins the image samples leave the FFT kernel -------------------------------
 @pytest.mark.parametrize("datatype,nfft,hop,height", [("cf32_le", 4096, 4096, 600), ("cf32_le", 4096, 2048, 4096),
                                                        ("ci16_le", 1024, 1024, 333), ("cu8", 256, 256, 256),
-                                                       ("ci16_be", 2048, 1024, 1000), ("ci8", 512, 300, 17)])
+                                                       ("ci16_be", 2048, 1024, 1000), ("ci8", 512, 300, 17),
+                                                       ("cu8", 256, 256, 300),        # more rows than bins: two-pass form
+                                                       ("cf32_le", 8192, 8192, 700),  # 32-point threads: two-pass form
+                                                       ("cf64_le", 1024, 512, 400)])  # fp64 arithmetic: two-pass form
 @pytest.mark.parametrize("colormap", [sa.CMAP_GRAYSCALE, sa.CMAP_HEATMAP])
 def test_waterfall_render_fused_equals_two_pass(svc, oracle, datatype, nfft, hop, height, colormap):
     """spec_waterfall_render with the compact tile (default) must give the very pixels of the two-pass form
