@@ -126,3 +126,31 @@ def test_fp64_family_all_variants(svc, oracle, nfft, datatype, hop_div, window):
     if datatype.startswith("cf64"):   # fp64 arithmetic, fp32 storage
         f32 = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_DB20_F32)
         assert f32.dtype == np.float32 and np.abs(f32 - got[:-1]).max() <= 2e-5
+
+
+# ---- values at the edges of fp32: overflow of |X|^2, underflow, NaN -------------------------------------
+@pytest.mark.parametrize("nfft", [1024, 4096, 16384])
+def test_extreme_magnitudes_and_nan(svc, oracle, nfft):
+    """|X|^2 overflows fp32 although |X| does not (the epilogue rescales), vanishing input ends at the 1e-10
+    floor (-200 dB, SS:81), and a NaN sample poisons exactly the lines that contain it."""
+    n_lines, hop = 6, nfft // 2
+    n = (n_lines - 1) * hop + nfft
+    t = np.arange(n)
+    tone = np.exp(2j * np.pi * 0.125 * t)
+    for amp, expect in ((1e25, 20 * np.log10(1e25 * nfft)), (1e-30, -200.0)):
+        x = np.empty(2 * n, dtype="<f4"); x[0::2], x[1::2] = (amp * tone).real, (amp * tone).imag
+        got = svc.compute_waterfall(x, 0, nfft, "cf32_le", n_lines, hop=hop)
+        ref = oracle.waterfall(x.view(np.uint8), 0, "cf32_le", nfft, hop, n_lines)
+        k = (nfft // 8 + nfft // 2) % nfft                      # the tone's bin after fftshift (SS:78)
+        assert np.all(np.isfinite(got))
+        assert np.abs(got[:, k] - ref[:, k]).max() <= 2e-3 and abs(float(got[0, k]) - expect) <= 1e-2
+        if amp < 1:
+            assert np.abs(got - ref).max() <= 1e-4               # everything sits on the floor
+    x = np.empty(2 * n, dtype="<f4"); x[0::2], x[1::2] = tone.real, tone.imag
+    x[2 * (2 * hop + 5)] = np.nan                                # sample 2 hop + 5: lines 1 and 2 contain it
+    got = svc.compute_waterfall(x, 0, nfft, "cf32_le", n_lines, hop=hop)
+    ref = oracle.waterfall(x.view(np.uint8), 0, "cf32_le", nfft, hop, n_lines)
+    bad = np.isnan(ref).all(axis=1)
+    assert list(bad) == [False, True, True, False, False, False]
+    assert np.isnan(got[bad]).all() and np.isfinite(got[~bad]).all()
+    check_fp32(got[~bad], ref[~bad], nfft)
