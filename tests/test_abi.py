@@ -32,8 +32,10 @@ def test_no_torch_in_the_abi():
     # the boundary is plain C: the library must not link libtorch / libc10
     import subprocess
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    assert "torch" not in out and "c10" not in out
-    assert "amdhip64" in out
+    # library NAMES only: the load addresses ldd prints may contain "c10" by chance (ASLR)
+    names = [line.split()[0] for line in out.splitlines() if line.strip()]
+    assert not any("torch" in n or "c10" in n for n in names), names
+    assert any("amdhip64" in n for n in names), names
 
 
 def test_dtype_table_matches_reference_rules():
