@@ -12,8 +12,11 @@
  *   - every call returns a spec_status; spec_last_error() gives the text.
  *   - the caller owns every buffer it passes; the library owns only what lives
  *     inside a spec_ctx (twiddle / window tables, staging and scratch memory).
- *   - a spec_ctx is bound to one GPU and one HIP stream and is not re-entrant;
- *     distinct contexts are independent (one per device / host thread).
+ *   - a spec_ctx is bound to one GPU and one HIP stream.  It may be shared by host
+ *     threads (the reference runs ExtractDownConvertService on a thread pool,
+ *     AsyncExtractDownConvertService.java:27-35): every call holds the context's lock,
+ *     so calls on one context are serialised; distinct contexts are independent and run
+ *     concurrently.  A call leaves the calling thread's current HIP device as it found it.
  *   - there is NO CPU backend: without a usable gfx950 device spec_create fails
  *     with SPEC_EDEVICE.
  *   - device-pointer calls are asynchronous on the context's stream; host-pointer
@@ -30,7 +33,7 @@ extern "C" {
 #endif
 
 #define SPECGPU_VERSION_MAJOR 0
-#define SPECGPU_VERSION_MINOR 1
+#define SPECGPU_VERSION_MINOR 2
 
 typedef struct spec_ctx spec_ctx;
 
@@ -111,7 +114,13 @@ void *spec_stream(const spec_ctx *ctx);
 /* Tuning / testing knobs (not needed for normal use):
  *   "force_generic" = 1  route every request through the generic (scalar-math) kernels
  *   "lines_per_wg"  = n  consecutive lines (Welch: segments) walked by one sub-line / workgroup (0 = automatic)
- *   "large_chunk_mb" = m scratch size of the four-step path (nfft >= 32768; default 1024 MiB)
+ *   "large_chunk_mb" = m scratch size of the two-launch four-step path (nfft >= 32768; default 1024 MiB)
+ *   "large_team" = 0 | 1 | 2   lines longer than the LDS holds (fp32 nfft >= 32768, fp64 nfft >= 16384): 1 (default)
+ *                     = one persistent launch that keeps the intermediate in each XCD's L2, for calls of >= 64 lines,
+ *                     with the two-launch path behind it as a guarded fall-back; 0 = two-launch path only; 2 = the
+ *                     persistent launch for any number of lines and no fall-back (the call then waits for the
+ *                     kernel and returns SPEC_EDEVICE if one of its bounded waits timed out)
+ *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 2)
  *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
  *   "render_fused" = 0 | 1   spec_waterfall_render stores only the bins the image samples (default 1; 0 = full
  *                     dB tile, then the colour kernel: the two forms give identical pixels)
@@ -201,11 +210,14 @@ spec_status spec_waterfall_render(spec_ctx *ctx, const void *iq, int iq_on_devic
  * reference tree, so window / overlap / scaling are explicit parameters here).
  * n_psd independent PSDs are computed in one call: PSD b uses n_seg segments
  * of nfft samples, hop apart, starting at byte start_byte + b*psd_stride_bytes.
- * Any datatype and any nfft of the spectrogram path; cf32 / ci16 / cu8 / ci8 with
- * 256 <= nfft <= 16384 take the fused fast path.
+ * Any datatype; nfft is ANY integer in 1 ... 65536 -- the reference's short-burst call passes
+ * the burst length itself (AnalysisDialogController.java:303-307), so lengths that are not a
+ * power of two are transformed by a plain fp64 DFT (O(nfft^2) per segment; the dialog's case is
+ * one segment of < 8192 samples).  cf32 / ci16 / cu8 / ci8 with a power-of-two 256 <= nfft <=
+ * 16384 take the fused fast path.
  * freq_out (may be NULL): nfft doubles, (k - nfft/2) fs / nfft, HOST memory.
- * psd_out: n_psd x nfft floats (fftshifted; 10 log10(P + 1e-20) when db != 0),
- * device memory when out_on_device != 0. */
+ * psd_out: n_psd x nfft floats (fftshifted: out[(k + nfft/2) % nfft] = P[k], also for odd nfft;
+ * 10 log10(P + 1e-20) when db != 0), device memory when out_on_device != 0. */
 spec_status spec_welch_psd(spec_ctx *ctx, const void *iq, int iq_on_device, uint64_t n_bytes,
                            uint64_t start_byte, uint64_t psd_stride_bytes, uint32_t n_psd,
                            spec_dtype dt, uint32_t nfft, uint32_t hop, uint32_t n_seg,
@@ -217,10 +229,12 @@ spec_status spec_welch_psd(spec_ctx *ctx, const void *iq, int iq_on_device, uint
  * (AnalysisDialogController.java:308-312): planar doubles data[0] = I, data[1] = Q as produced by
  * ExtractDownConvertService -- in host memory, or (in_on_device != 0) still on the device where
  * spec_down_convert left them.  Every whole segment of the signal is used
- * (n_seg = (n_samples - nfft)/hop + 1); fp64 pipeline.  freq_out / psd_out: nfft values, host. */
+ * (n_seg = (n_samples - nfft)/hop + 1); fp64 pipeline end to end, any nfft in 1 ... 65536 (the
+ * dialog passes nfft = data[0].length for bursts shorter than 8192 samples, ADC:303-307).
+ * freq_out / psd_out: nfft doubles each, host memory -- the two rows the reference returns. */
 spec_status spec_welch_psd_planar_f64(spec_ctx *ctx, const double *re, const double *im, int in_on_device,
                                       uint64_t n_samples, uint32_t nfft, uint32_t hop, spec_window window,
-                                      spec_psd_scaling scaling, double fs, int db, double *freq_out, float *psd_out);
+                                      spec_psd_scaling scaling, double fs, int db, double *freq_out, double *psd_out);
 
 /* ---- burst analysis (the Analysis dialog) ---------- */
 

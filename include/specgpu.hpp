@@ -45,11 +45,10 @@ public:
     // returns {freq, psd}
     std::vector<std::vector<double>> calculatePsdWelch(const double *re, const double *im, uint64_t n, double fs,
                                                        uint32_t nfft) const {
-        std::vector<double> f(nfft);
-        std::vector<float> p(nfft);
-        check(spec_welch_psd_planar_f64(ctx_, re, im, 0, n, nfft, nfft / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY, fs, 0,
-                                        f.data(), p.data()), ctx_);
-        return {f, std::vector<double>(p.begin(), p.end())};
+        std::vector<double> f(nfft), p(nfft);
+        check(spec_welch_psd_planar_f64(ctx_, re, im, 0, n, nfft, nfft > 1 ? nfft / 2 : 1, SPEC_WIN_HANN, SPEC_PSD_DENSITY,
+                                        fs, 0, f.data(), p.data()), ctx_);
+        return {f, p};
     }
 
     // ExtractDownConvertService.extractAndDownConvert (ExtractDownConvertService.java:54-117): {I, Q} of

@@ -12,6 +12,10 @@ import org.springframework.stereotype.Service;
  * libspecgpu.so (HIP kernels for MI355X) through the JNI shim
  * integration/jni/specgpu_jni.c; this class holds no FFT code.
  *
+ * <p>Thread safety: the reference's service is stateless and may be called from any thread.  So
+ * may this one -- the native context takes its own lock for the length of every call (see
+ * include/specgpu.h), concurrent callers are serialised inside the library.
+ *
  * Added on top of the reference API: {@link #computeWaterfall} (the whole slice
  * loop of MainController.updateDisplay in one call) and {@link #welchPsd}
  * (the PSD dialog's Welch estimate).
@@ -95,19 +99,16 @@ public class SpectralService implements AutoCloseable {
 
     /**
      * Same argument shape as {@code PowerSpectralDensity.calculatePsdWelch(data, fs, nfft)} in the
-     * PSD dialog: {@code data[0]} = I, {@code data[1]} = Q.  Hann window, 50 % overlap, density
-     * scaling, linear power; returns {frequency axis, psd}.
+     * PSD dialog: {@code data[0]} = I, {@code data[1]} = Q.  {@code nfft} is any positive length --
+     * the dialog passes {@code data[0].length} for bursts shorter than 8192 samples.  Hann window,
+     * 50 % overlap, density scaling, linear power, fp64 throughout; returns {frequency axis, psd}.
      */
     public double[][] calculatePsdWelch(double[][] data, double sampleRate, int nfft) {
-        double[] freq = new double[nfft];
-        float[] psd = new float[nfft];
-        nativeWelchPlanar(handle, data[0], data[1], nfft, nfft / 2, WINDOW_HANN, PSD_DENSITY, sampleRate,
-                false, freq, psd);
-        double[] wide = new double[nfft];
-        for (int i = 0; i < nfft; i++) {
-            wide[i] = psd[i];
-        }
-        return new double[][] {freq, wide};
+        double[] freq = new double[Math.max(nfft, 0)];
+        double[] psd = new double[Math.max(nfft, 0)];
+        nativeWelchPlanar(handle, data[0], data[1], nfft, Math.max(nfft / 2, 1), WINDOW_HANN, PSD_DENSITY,
+                sampleRate, false, freq, psd);
+        return new double[][] {freq, psd};
     }
 
     /**
@@ -151,7 +152,7 @@ public class SpectralService implements AutoCloseable {
                                                      int[] argb);
     private static native void nativeWelchPlanar(long handle, double[] re, double[] im, int nfft, int hop,
                                                  int window, int scaling, double sampleRate, boolean decibel,
-                                                 double[] freq, float[] psd);
+                                                 double[] freq, double[] psd);
     private static native void nativeTrace(long handle, int which, double[] re, double[] im, double alpha,
                                            double sampleRate, double centerFreq, double[] out);
     private static native int nativeDtype(String datatype);

@@ -8,9 +8,10 @@
  * SigMfHelper.java:84) is a direct buffer, so GetDirectBufferAddress gives the
  * mapped bytes without a copy.
  *
- * Build (needs a JDK for jni.h; none exists in the authoring container, so this
- * file is compiled by `python -m spectral_analyzer_amd.build --jni` only when
- * JAVA_HOME is set):
+ * Build (needs a JDK for jni.h; `python -m spectral_analyzer_amd.build --jni` compiles it when
+ * JAVA_HOME is set).  The authoring container has no JDK: there the file is compiled with
+ * -Wall -Werror against the JNI subset in tests/jni_stub/jni.h and its entry points are CALLED
+ * through a fake JNIEnv by tests/jni_stub/harness.c (tests/test_jni_shim.py):
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
  *       integration/jni/specgpu_jni.c -Lspectral_analyzer_amd/lib -lspecgpu \
  *       -o spectral_analyzer_amd/lib/libspecgpu_jni.so
@@ -23,15 +24,19 @@
 #define JNI_FN(name) Java_net_kcundercover_spectral_1analyzer_services_SpectralService_##name
 
 /* spec_status -> the exception the reference's own code path would raise */
-static void throw_status(JNIEnv *env, spec_ctx *ctx, spec_status st) {
+static void throw_msg(JNIEnv *env, spec_status st, const char *msg) {
     const char *cls = "java/lang/RuntimeException";
     if (st == SPEC_EINVAL) cls = "java/lang/IllegalArgumentException";         /* commons-math3 MathIllegalArgumentException */
     else if (st == SPEC_ERANGE) cls = "java/lang/IndexOutOfBoundsException";  /* ByteBuffer absolute getters */
     else if (st == SPEC_ENOMEM) cls = "java/lang/OutOfMemoryError";
     else if (st == SPEC_EUNSUPPORTED) cls = "java/lang/UnsupportedOperationException";
     jclass c = (*env)->FindClass(env, cls);
-    if (c) (*env)->ThrowNew(env, c, spec_last_error(ctx));
+    if (c) (*env)->ThrowNew(env, c, msg);
 }
+/* a failure reported by the library: its own text */
+static void throw_status(JNIEnv *env, spec_ctx *ctx, spec_status st) { throw_msg(env, st, spec_last_error(ctx)); }
+/* a failure found in the shim itself (array too short, not a direct buffer): never the library's stale text */
+static void throw_shim(JNIEnv *env, const char *msg) { throw_msg(env, SPEC_EINVAL, msg); }
 
 JNIEXPORT jlong JNICALL JNI_FN(nativeCreate)(JNIEnv *env, jclass k, jint device, jint flags) {
     (void)k;
@@ -54,7 +59,8 @@ JNIEXPORT void JNICALL JNI_FN(nativeComputeMagnitudes)(JNIEnv *env, jclass k, jl
     spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
     void *base = (*env)->GetDirectBufferAddress(env, buffer);
     jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
-    if (!base || cap < 0) { throw_status(env, ctx, SPEC_EINVAL); return; }
+    if (!base || cap < 0) { throw_shim(env, "computeMagnitudes: not a direct buffer"); return; }
+    if (nfft < 0 || (*env)->GetArrayLength(env, out) < nfft) { throw_shim(env, "computeMagnitudes: out is shorter than nfft"); return; }
     const char *dt = (*env)->GetStringUTFChars(env, datatype, NULL);
     jdouble *o = (*env)->GetDoubleArrayElements(env, out, NULL);
     spec_status st = spec_compute_magnitudes(ctx, base, (uint64_t)cap, (int64_t)startByte, (uint32_t)nfft, dt,
@@ -72,8 +78,9 @@ JNIEXPORT void JNICALL JNI_FN(nativeWaterfall)(JNIEnv *env, jclass k, jlong h, j
     spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
     void *base = (*env)->GetDirectBufferAddress(env, buffer);
     jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
-    if (!base || cap < 0 || (jlong)(*env)->GetArrayLength(env, out) < nLines * (jlong)nfft) {
-        throw_status(env, ctx, SPEC_EINVAL);
+    if (!base || cap < 0) { throw_shim(env, "computeWaterfall: not a direct buffer"); return; }
+    if (nfft < 0 || nLines < 0 || (jlong)(*env)->GetArrayLength(env, out) < nLines * (jlong)nfft) {
+        throw_shim(env, "computeWaterfall: out is shorter than nLines * nfft");
         return;
     }
     jfloat *o = (*env)->GetFloatArrayElements(env, out, NULL);
@@ -92,7 +99,11 @@ JNIEXPORT void JNICALL JNI_FN(nativeWelch)(JNIEnv *env, jclass k, jlong h, jobje
     spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
     void *base = (*env)->GetDirectBufferAddress(env, buffer);
     jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
-    if (!base || cap < 0) { throw_status(env, ctx, SPEC_EINVAL); return; }
+    if (!base || cap < 0) { throw_shim(env, "welchPsd: not a direct buffer"); return; }
+    if (nfft < 0 || (*env)->GetArrayLength(env, freq) < nfft || (*env)->GetArrayLength(env, psd) < nfft) {
+        throw_shim(env, "welchPsd: freq / psd are shorter than nfft");
+        return;
+    }
     jdouble *f = (*env)->GetDoubleArrayElements(env, freq, NULL);
     jfloat *p = (*env)->GetFloatArrayElements(env, psd, NULL);
     spec_status st = spec_welch_psd(ctx, base, 0, (uint64_t)cap, (uint64_t)startByte, 0, 1, (spec_dtype)dtype,
@@ -114,8 +125,9 @@ JNIEXPORT void JNICALL JNI_FN(nativeWaterfallRender)(JNIEnv *env, jclass k, jlon
     spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
     void *base = (*env)->GetDirectBufferAddress(env, buffer);
     jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
-    if (!base || cap < 0 || (jlong)(*env)->GetArrayLength(env, argb) < (jlong)width * height) {
-        throw_status(env, ctx, SPEC_EINVAL);
+    if (!base || cap < 0) { throw_shim(env, "waterfallRender: not a direct buffer"); return; }
+    if (width < 0 || height < 0 || (jlong)(*env)->GetArrayLength(env, argb) < (jlong)width * height) {
+        throw_shim(env, "waterfallRender: argb is shorter than width * height");
         return;
     }
     jint *px = (*env)->GetIntArrayElements(env, argb, NULL);
@@ -129,18 +141,22 @@ JNIEXPORT void JNICALL JNI_FN(nativeWaterfallRender)(JNIEnv *env, jclass k, jlon
 /* PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft) -- ADC:308-312 */
 JNIEXPORT void JNICALL JNI_FN(nativeWelchPlanar)(JNIEnv *env, jclass k, jlong h, jdoubleArray re, jdoubleArray im,
                                                   jint nfft, jint hop, jint window, jint scaling, jdouble fs,
-                                                  jboolean db, jdoubleArray freq, jfloatArray psd) {
+                                                  jboolean db, jdoubleArray freq, jdoubleArray psd) {
     (void)k;
     spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
     jsize n = (*env)->GetArrayLength(env, re);
-    if ((*env)->GetArrayLength(env, im) != n) { throw_status(env, ctx, SPEC_EINVAL); return; }
+    if ((*env)->GetArrayLength(env, im) != n) { throw_shim(env, "calculatePsdWelch: data[0] and data[1] differ in length"); return; }
+    if (nfft < 0 || (*env)->GetArrayLength(env, freq) < nfft || (*env)->GetArrayLength(env, psd) < nfft) {
+        throw_shim(env, "calculatePsdWelch: freq / psd are shorter than nfft");
+        return;
+    }
     jdouble *r = (*env)->GetDoubleArrayElements(env, re, NULL);
     jdouble *i = (*env)->GetDoubleArrayElements(env, im, NULL);
     jdouble *f = (*env)->GetDoubleArrayElements(env, freq, NULL);
-    jfloat *p = (*env)->GetFloatArrayElements(env, psd, NULL);
+    jdouble *p = (*env)->GetDoubleArrayElements(env, psd, NULL);
     spec_status st = spec_welch_psd_planar_f64(ctx, r, i, 0, (uint64_t)n, (uint32_t)nfft, (uint32_t)hop,
                                                (spec_window)window, (spec_psd_scaling)scaling, fs, db ? 1 : 0, f, p);
-    (*env)->ReleaseFloatArrayElements(env, psd, p, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, psd, p, st == SPEC_OK ? 0 : JNI_ABORT);
     (*env)->ReleaseDoubleArrayElements(env, freq, f, st == SPEC_OK ? 0 : JNI_ABORT);
     (*env)->ReleaseDoubleArrayElements(env, im, i, JNI_ABORT);
     (*env)->ReleaseDoubleArrayElements(env, re, r, JNI_ABORT);
@@ -164,7 +180,7 @@ JNIEXPORT void JNICALL JNI_FN(nativeTrace)(JNIEnv *env, jclass k, jlong h, jint 
     spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
     jsize n = (*env)->GetArrayLength(env, re);
     if ((*env)->GetArrayLength(env, im) != n || (*env)->GetArrayLength(env, out) < (which ? n - 1 : n)) {
-        throw_status(env, ctx, SPEC_EINVAL);
+        throw_shim(env, "trace: array lengths do not match");
         return;
     }
     jdouble *r = (*env)->GetDoubleArrayElements(env, re, NULL);
@@ -200,7 +216,7 @@ JNIEXPORT void JNICALL EDC_FN(nativeExtractAndDownConvert)(JNIEnv *env, jclass k
     jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
     if (!base || cap < 0 || startSample < 0 || count < 0 || down <= 0 ||
         (*env)->GetArrayLength(env, re) < count / down || (*env)->GetArrayLength(env, im) < count / down) {
-        throw_status(env, ctx, SPEC_EINVAL);
+        throw_shim(env, "extractAndDownConvert: bad buffer, negative argument or output arrays shorter than count / down");
         return;
     }
     const char *s = (*env)->GetStringUTFChars(env, datatype, NULL);

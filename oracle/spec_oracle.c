@@ -184,7 +184,7 @@ static void line_spectrum(const uint8_t *buf, uint64_t start_byte, uint32_t nfft
         decode_kind(buf, start_byte, i, kind, be, &re[i], &im[i]);
         if (win) { re[i] *= win[i]; im[i] *= win[i]; }
     }
-    if (nfft > 1) fft_forward_tw(re, im, nfft, wr, wi);
+    if (nfft > 1 && (nfft & (nfft - 1)) == 0) fft_forward_tw(re, im, nfft, wr, wi);
 }
 
 /* SpectralService.java:33-85 */
@@ -264,24 +264,58 @@ int so_welch_psd(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
                  const char *dt, int cf64_decode, uint32_t nfft, uint32_t hop,
                  uint32_t n_seg, int window, int scaling, double fs, int psd_db,
                  double *freq_out, double *psd_out) {
-    if (nfft == 0 || (nfft & (nfft - 1)) != 0 || hop == 0 || n_seg == 0) return -1;
+    if (nfft == 0 || hop == 0 || n_seg == 0) return -1;
+    const int pow2 = (nfft & (nfft - 1)) == 0;
     uint64_t bps = (uint64_t)so_bytes_per_sample(dt);
     if (start_byte + ((uint64_t)(n_seg - 1) * hop + nfft) * bps > capacity) return -1;
-    double *re = (double *)malloc(sizeof(double) * nfft * 4), *wr, *wi;
+    double *re = (double *)malloc(sizeof(double) * nfft * 6), *wr = NULL, *wi = NULL;
     if (!re) return -1;
-    if (make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
-    double *im = re + nfft, *win = im + nfft, *acc = win + nfft;
+    double *im = re + nfft, *win = im + nfft, *acc = win + nfft, *xr = acc + nfft, *xi = xr + nfft;
+    if (pow2) {
+        if (make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
+    } else {
+        /* AnalysisDialogController.java:303-307 hands JDSP the burst length itself when the burst is
+         * shorter than 8192 samples: any integer.  Plain O(N^2) DFT, X[k] = sum x[n] W^(nk mod N),
+         * with the full table W^m = exp(-2 pi i m / N) evaluated in long double and rounded once. */
+        wr = (double *)malloc(sizeof(double) * nfft);
+        wi = (double *)malloc(sizeof(double) * nfft);
+        if (!wr || !wi) { free(re); free(wr); free(wi); return -1; }
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (uint32_t m = 0; m < nfft; m++) {
+            long double a = -two_pi * (long double)m / (long double)nfft;
+            wr[m] = (double)cosl(a);
+            wi[m] = (double)sinl(a);
+        }
+    }
     make_window(win, nfft, window);
     double s1 = 0, s2 = 0;
     for (uint32_t i = 0; i < nfft; i++) { s1 += win[i]; s2 += win[i] * win[i]; acc[i] = 0; }
+    if (!(s2 > 0)) { free(re); free(wr); free(wi); return -1; }  /* Hann of one point */
     for (uint32_t s = 0; s < n_seg; s++) {
-        line_spectrum(buf, start_byte + (uint64_t)s * hop * bps, nfft, dt,
-                      cf64_decode, win, wr, wi, re, im);
+        if (pow2) {
+            line_spectrum(buf, start_byte + (uint64_t)s * hop * bps, nfft, dt,
+                          cf64_decode, win, wr, wi, re, im);
+        } else {
+            line_spectrum(buf, start_byte + (uint64_t)s * hop * bps, nfft, dt,
+                          cf64_decode, win, wr, wi, xr, xi);  /* decode + window only (see below) */
+            for (uint32_t k = 0; k < nfft; k++) {
+                double ar = 0, ai = 0;
+                uint32_t m = 0;
+                for (uint32_t n = 0; n < nfft; n++) {
+                    ar += xr[n] * wr[m] - xi[n] * wi[m];
+                    ai += xr[n] * wi[m] + xi[n] * wr[m];
+                    m += k;
+                    if (m >= nfft) m -= nfft;
+                }
+                re[k] = ar;
+                im[k] = ai;
+            }
+        }
         for (uint32_t i = 0; i < nfft; i++) acc[i] += re[i] * re[i] + im[i] * im[i];
     }
     double norm = (scaling == SO_PSD_DENSITY) ? 1.0 / (fs * s2) : 1.0 / (s1 * s1);
     norm /= (double)n_seg;
-    uint32_t half = nfft / 2;
+    uint32_t half = nfft / 2;  /* numpy.fft.fftshift for odd lengths too: out[(k + N/2) % N] = P[k] */
     for (uint32_t i = 0; i < nfft; i++) {
         uint32_t sidx = (i + half) % nfft;
         double p = acc[i] * norm;

@@ -22,6 +22,10 @@
 using namespace specgpu;
 
 struct spec_ctx {
+    // every entry point that takes a context holds this lock for the whole call: a context may be shared
+    // by host threads (the reference runs ExtractDownConvertService on a pool, AsyncExtractDownConvertService
+    // .java:27-35,52-55), their calls are serialised.  Recursive: entry points call each other.
+    std::recursive_mutex mu;
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -31,14 +35,20 @@ struct spec_ctx {
     std::map<uint32_t, void *> twiddles;
     std::map<uint32_t, void *> windows;
     std::map<uint32_t, std::pair<double, double>> window_sums;  // sum w, sum w^2
+    // tables of arbitrary (non power-of-two) lengths, keyed by the length: plain-DFT Welch path
+    std::map<uint32_t, void *> twiddles_n, windows_n;
+    std::map<uint32_t, std::pair<double, double>> window_sums_n;
     // grow-only device scratch
     void *stage_in = nullptr;  size_t stage_in_bytes = 0;
     void *stage_out = nullptr; size_t stage_out_bytes = 0;
     void *scratch = nullptr;   size_t scratch_bytes = 0;   // large-N transposes, Welch slabs
     void *scratch2 = nullptr;  size_t scratch2_bytes = 0;  // fallback Welch: power lines + accumulator
-    void *planar = nullptr;    size_t planar_bytes = 0;    // spec_welch_psd_planar_f64: interleaved copy of the burst
+    void *planar = nullptr;    size_t planar_bytes = 0;
+    void *team_scratch = nullptr; size_t team_scratch_bytes = 0;  // spec_k_team.hip: ring slots of every team
+    void *team_sync = nullptr;    size_t team_sync_bytes = 0;     //                   tickets, ring counters, abort word    // spec_welch_psd_planar_f64: interleaved copy of the burst
     // tuning / testing knobs (spec_set_option)
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
+    int64_t opt_large_team = 1, opt_large_ring = 2;
     int n_cu = 256;
     // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
     // them against the compute stream, created on first use
@@ -59,6 +69,9 @@ struct spec_ctx {
 };
 
 static thread_local std::string g_create_err;
+// the calling thread's own last failure (a context shared by threads has one `err` for all of them)
+static thread_local std::string t_err;
+static thread_local const spec_ctx *t_err_ctx = nullptr;
 
 static spec_status fail(spec_ctx *c, spec_status st, const char *fmt, ...) {
     char buf[512];
@@ -66,8 +79,45 @@ static spec_status fail(spec_ctx *c, spec_status st, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_err = buf;
+    if (c) {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        c->err = buf;
+        t_err = buf;
+        t_err_ctx = c;
+    } else {
+        g_create_err = buf;
+    }
     return st;
+}
+
+// Scope of one entry point: serialises the context and makes its device current for the calling thread,
+// restoring the caller's device on the way out (a context bound to device k must not leave a PyTorch
+// thread on device k).
+struct Enter {
+    spec_ctx *c;
+    int prev = -1;
+    bool switched = false;
+    explicit Enter(spec_ctx *ctx) : c(ctx) {
+        if (!c) return;
+        c->mu.lock();
+        if (hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    void leave() {
+        if (!c) return;
+        if (switched) (void)hipSetDevice(prev);
+        c->mu.unlock();
+        c = nullptr;
+    }
+    ~Enter() { leave(); }
+    Enter(const Enter &) = delete;
+    Enter &operator=(const Enter &) = delete;
+};
+
+// overflow-checked a * b + c in uint64 (false on wrap): every byte count derived from caller-supplied counts
+static bool mul_add_u64(uint64_t a, uint64_t b, uint64_t c, uint64_t *out) {
+    uint64_t p;
+    if (__builtin_mul_overflow(a, b, &p)) return false;
+    return !__builtin_add_overflow(p, c, out);
 }
 
 #define HIP_TRY(c, expr)                                                                     \
@@ -114,7 +164,11 @@ const char *spec_status_string(spec_status st) {
     }
 }
 
-const char *spec_last_error(const spec_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+const char *spec_last_error(const spec_ctx *ctx) {
+    if (!ctx) return g_create_err.c_str();
+    if (t_err_ctx == ctx) return t_err.c_str();  // this thread's own failure on a shared context
+    return ctx->err.c_str();
+}
 
 spec_dtype spec_dtype_from_sigmf(const char *s) {
     if (!s) return SPEC_DT_UNKNOWN;
@@ -163,17 +217,19 @@ spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx *
     c->device = device;
     c->flags = flags;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, SPEC_EDEVICE, "hipSetDevice(%d) failed", device); }
-    if (hip_stream) {
-        c->stream = static_cast<hipStream_t>(hip_stream);
-    } else if (flags & SPEC_FLAG_NULL_STREAM) {
-        c->stream = nullptr;  // the default stream: ordered with everything else the process queues on it
-    } else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete c;
+    {
+        Enter g(c);  // the caller's current device is restored on the way out
+        if (g.prev != device && !g.switched) { g.leave(); delete c; return fail(nullptr, SPEC_EDEVICE, "hipSetDevice(%d) failed", device); }
+        if (hip_stream) {
+            c->stream = static_cast<hipStream_t>(hip_stream);
+        } else if (flags & SPEC_FLAG_NULL_STREAM) {
+            c->stream = nullptr;  // the default stream: ordered with everything else the process queues on it
+        } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess) {
+            c->own_stream = true;
+        } else {
+            g.leave(); delete c;
             return fail(nullptr, SPEC_EDEVICE, "hipStreamCreate failed");
         }
-        c->own_stream = true;
     }
     *out = c;
     return SPEC_OK;
@@ -181,15 +237,19 @@ spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx *
 
 void spec_destroy(spec_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    Enter g(c);
     (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->twiddles) (void)hipFree(kv.second);
     for (auto &kv : c->windows) (void)hipFree(kv.second);
+    for (auto &kv : c->twiddles_n) (void)hipFree(kv.second);
+    for (auto &kv : c->windows_n) (void)hipFree(kv.second);
     (void)hipFree(c->stage_in);
     (void)hipFree(c->stage_out);
     (void)hipFree(c->scratch);
     (void)hipFree(c->scratch2);
     (void)hipFree(c->planar);
+    (void)hipFree(c->team_scratch);
+    (void)hipFree(c->team_sync);
     (void)hipFree(c->sel_dev);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
@@ -198,12 +258,13 @@ void spec_destroy(spec_ctx *c) {
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    g.leave();
     delete c;
 }
 
 spec_status spec_sync(spec_ctx *c) {
     if (!c) return SPEC_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
+    Enter g(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPEC_OK;
 }
@@ -212,11 +273,14 @@ void *spec_stream(const spec_ctx *c) { return c ? static_cast<void *>(c->stream)
 
 spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!key) return fail(c, SPEC_EINVAL, "spec_set_option: null key");
     if (!strcmp(key, "force_generic")) c->opt_force_generic = value;
     else if (!strcmp(key, "lines_per_wg")) c->opt_lines_per_wg = value < 0 ? 0 : value;
     else if (!strcmp(key, "large_chunk_mb")) c->opt_large_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
+    else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 1 ? 1 : (value > 4 ? 4 : value);
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
     else if (!strcmp(key, "readahead_lines")) { c->opt_readahead_lines = value < 0 ? 0 : value; c->ra.n = 0; }
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
@@ -290,6 +354,55 @@ static spec_status get_window(spec_ctx *c, int log2n, bool f64, spec_window w, c
     return SPEC_OK;
 }
 
+// Tables of an arbitrary length N (the plain-DFT Welch path): W_N^m as cx<double>[N] and the periodic Hann
+// window as double[N] (nullptr for the rectangular one), long double on the host, rounded once.
+static spec_status get_tables_n(spec_ctx *c, uint32_t n, spec_window w, const void **tw, const void **win, double *s1,
+                                double *s2) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    auto upload = [&](const std::vector<double> &host, void **dev) -> spec_status {
+        HIP_TRY(c, hipMalloc(dev, host.size() * sizeof(double)));
+        hipError_t e = hipMemcpyAsync(*dev, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host vector dies at return
+        if (e != hipSuccess) { (void)hipFree(*dev); *dev = nullptr; return fail(c, SPEC_EDEVICE, "table upload: %s", hipGetErrorString(e)); }
+        return SPEC_OK;
+    };
+    auto it = c->twiddles_n.find(n);
+    if (it == c->twiddles_n.end()) {
+        std::vector<double> host;
+        try { host.resize(2 * (size_t)n); } catch (...) { return fail(c, SPEC_ENOMEM, "out of host memory"); }
+        for (uint32_t m = 0; m < n; ++m) {
+            const long double a = -two_pi * (long double)m / (long double)n;
+            host[2 * m] = (double)cosl(a);
+            host[2 * m + 1] = (double)sinl(a);
+        }
+        void *dev = nullptr;
+        spec_status st = upload(host, &dev);
+        if (st != SPEC_OK) return st;
+        it = c->twiddles_n.emplace(n, dev).first;
+    }
+    *tw = it->second;
+    if (w == SPEC_WIN_RECT) { *win = nullptr; *s1 = *s2 = (double)n; return SPEC_OK; }
+    auto iw = c->windows_n.find(n);
+    if (iw == c->windows_n.end()) {
+        std::vector<double> host;
+        try { host.resize(n); } catch (...) { return fail(c, SPEC_ENOMEM, "out of host memory"); }
+        double a1 = 0, a2 = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            host[i] = (double)(0.5L - 0.5L * cosl(two_pi * (long double)i / (long double)n));
+            a1 += host[i]; a2 += host[i] * host[i];
+        }
+        void *dev = nullptr;
+        spec_status st = upload(host, &dev);
+        if (st != SPEC_OK) return st;
+        iw = c->windows_n.emplace(n, dev).first;
+        c->window_sums_n[n] = {a1, a2};
+    }
+    *win = iw->second;
+    *s1 = c->window_sums_n[n].first;
+    *s2 = c->window_sums_n[n].second;
+    return SPEC_OK;
+}
+
 static spec_status grow(spec_ctx *c, void **buf, size_t *have, size_t need) {
     if (*have >= need) return SPEC_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -338,12 +451,49 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     if (st != SPEC_OK) return st;
     const uint64_t out_esz = fmt >= SPEC_OUT_DB20_F64 ? 8 : 4, nfft = 1ull << log2n;
     if (large) {
-        // four-step path: chunks of lines whose scratch stays inside the Infinity Cache
         const void *tw1 = nullptr, *tw2 = nullptr;
         if ((st = get_twiddles(c, l1, f64, &tw1)) != SPEC_OK) return st;
         if ((st = get_twiddles(c, l2, f64, &tw2)) != SPEC_OK) return st;
         const size_t per_line = large_scratch_bytes_per_line(log2n, f64);
-        uint64_t chunk = ((uint64_t)c->opt_large_chunk_mb << 20) / per_line;
+        // One persistent launch with the intermediate kept in each XCD's L2 (spec_k_team.hip); behind it, unless
+        // "large_team" = 2, the two-launch path as guarded kernels that run only if a bounded wait of the team
+        // kernel timed out (grid not co-resident: a shared GPU)
+        const uint32_t *run_if = nullptr;
+        const bool team = c->opt_large_team == 2 || (c->opt_large_team == 1 && n_lines >= 64);
+        if (team) {
+            uint32_t teams_max = 0;
+            const uint32_t ring = (uint32_t)c->opt_large_ring;
+            hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, nullptr, ring, nullptr, c->n_cu, &teams_max, true, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team query: %s", hipGetErrorString(e));
+            if ((st = grow(c, &c->team_scratch, &c->team_scratch_bytes, (size_t)(teams_max ? teams_max : 1) * ring * per_line)) != SPEC_OK) return st;
+            if ((st = grow(c, &c->team_sync, &c->team_sync_bytes, large_team_sync_bytes())) != SPEC_OK) return st;
+        }
+        for (uint64_t done = 0; team && done < n_lines;) {
+            const uint64_t nl = n_lines - done < 0x40000000ull ? n_lines - done : 0x40000000ull;  // 32-bit line index
+            uint32_t teams_max = 0;
+            HIP_TRY(c, hipMemsetAsync(c->team_sync, 0, large_team_sync_bytes(), c->stream));
+            a.n_lines = nl;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, c->team_scratch, (uint32_t)c->opt_large_ring,
+                                               static_cast<uint32_t *>(c->team_sync), c->n_cu, &teams_max, false, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team launch: %s", hipGetErrorString(e));
+            done += nl;
+            if (done < n_lines || c->opt_large_team == 2) {
+                // more than one team launch (> 2^30 lines), or no fall-back wanted: check this one now
+                uint32_t aborted = 0;
+                HIP_TRY(c, hipMemcpyAsync(&aborted, static_cast<uint32_t *>(c->team_sync) + large_team_abort_word(), 4,
+                                          hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (aborted) return fail(c, SPEC_EDEVICE, "large-N team kernel: a bounded wait timed out (grid not co-resident)");
+            }
+        }
+        if (team) {
+            if (c->opt_large_team == 2) return SPEC_OK;
+            run_if = static_cast<uint32_t *>(c->team_sync) + large_team_abort_word();
+        }
+        // four-step path as two launches per chunk of lines
+        uint64_t chunk = ((uint64_t)(team ? 128 : c->opt_large_chunk_mb) << 20) / per_line;
         if (chunk == 0) chunk = 1;
         if (chunk > n_lines) chunk = n_lines;
         if ((st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)chunk * per_line)) != SPEC_OK) return st;
@@ -351,7 +501,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             a.n_lines = n_lines - done < chunk ? n_lines - done : chunk;
             a.iq = d_first + done * (uint64_t)hop * a.bps;
             a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
-            hipError_t e = launch_spectro_large(a, log2n, f64, tw1, tw2, c->scratch, c->stream);
+            hipError_t e = launch_spectro_large(a, log2n, f64, tw1, tw2, c->scratch, c->stream, run_if);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N launch: %s", hipGetErrorString(e));
         }
         return SPEC_OK;
@@ -438,14 +588,20 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
                                   spec_dtype dt, uint32_t nfft, uint32_t hop, uint64_t n_lines, spec_window window,
                                   spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device,
                                   const int32_t *d_sel, uint32_t sel_row) {
+    if (!c) return SPEC_EINVAL;
+    Enter g(c);
     int log2n = 0;
     spec_status st = check_common(c, iq, out, dt, nfft, hop, window, &log2n);
     if (st != SPEC_OK) return st;
     if (out_fmt < SPEC_OUT_DB20_F32 || out_fmt > SPEC_OUT_POW_F64) return fail(c, SPEC_EINVAL, "bad out_fmt %d", out_fmt);
     if (n_lines == 0) return SPEC_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t bps = spec_bytes_per_sample(dt), out_esz = out_fmt >= SPEC_OUT_DB20_F64 ? 8 : 4;
     const uint64_t row = d_sel ? sel_row : nfft;  // elements per output line
+    {
+        uint64_t tile_bytes = 0;
+        if (!mul_add_u64(n_lines, row * out_esz, 0, &tile_bytes))
+            return fail(c, SPEC_ERANGE, "%llu lines of %u bins do not fit a 64-bit byte count", (unsigned long long)n_lines, nfft);
+    }
     // MainController.java:987 -- lines whose last byte is inside the buffer
     uint64_t n_valid = spec_count_lines(n_bytes, start_byte, dt, nfft, hop);
     if (n_valid > n_lines) n_valid = n_lines;
@@ -646,6 +802,7 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
 spec_status spec_compute_magnitudes(spec_ctx *c, const void *buffer, uint64_t capacity, int64_t start_byte,
                                     uint32_t nfft, const char *datatype, int big_endian, double *out) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!buffer || !out || !datatype) return fail(c, SPEC_EINVAL, "null argument");
     if (nfft == 0 || (nfft & (nfft - 1)) != 0) return fail(c, SPEC_EINVAL, "nfft = %u is not a power of two", nfft);
     // datatype: startsWith rules of SS:35-38; byte order is the buffer's (SMH:87-91)
@@ -708,26 +865,40 @@ spec_status spec_compute_magnitudes(spec_ctx *c, const void *buffer, uint64_t ca
                           SPEC_OUT_DB20_F64, -150.0, out, 0);
 }
 
-spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
-                           uint64_t psd_stride_bytes, uint32_t n_psd, spec_dtype dt, uint32_t nfft, uint32_t hop,
-                           uint32_t n_seg, spec_window window, spec_psd_scaling scaling, double fs, int db,
-                           double *freq_out, float *psd_out, int out_on_device) {
-    int log2n = 0;
-    spec_status st = check_common(c, iq, psd_out, dt, nfft, hop, window, &log2n);
-    if (st != SPEC_OK) return st;
+// Shared body of spec_welch_psd (float PSDs) and spec_welch_psd_planar_f64 (double PSDs, out_f64).
+// nfft may be ANY positive integer: the reference's short-burst call passes the burst length itself
+// (AnalysisDialogController.java:303-307); lengths that are not a power of two take the plain fp64 DFT.
+static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
+                              uint64_t psd_stride_bytes, uint32_t n_psd, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                              uint32_t n_seg, spec_window window, spec_psd_scaling scaling, double fs, int db,
+                              double *freq_out, void *psd_out_v, int out_on_device, bool out_f64) {
+    if (!c) return SPEC_EINVAL;
+    Enter g(c);
+    if (!iq || !psd_out_v) return fail(c, SPEC_EINVAL, "null buffer");
+    if (!dtype_valid(dt)) return fail(c, SPEC_EINVAL, "bad spec_dtype %d", dt);
+    if (nfft == 0) return fail(c, SPEC_EINVAL, "nfft must be >= 1");
+    if (hop == 0) return fail(c, SPEC_EINVAL, "hop must be >= 1");
+    if (window != SPEC_WIN_RECT && window != SPEC_WIN_HANN) return fail(c, SPEC_EINVAL, "bad window %d", window);
     if (n_seg == 0 || n_psd == 0) return fail(c, SPEC_EINVAL, "n_seg and n_psd must be >= 1");
     if (!(fs > 0)) return fail(c, SPEC_EINVAL, "fs must be positive");
     if (scaling != SPEC_PSD_DENSITY && scaling != SPEC_PSD_SPECTRUM) return fail(c, SPEC_EINVAL, "bad scaling");
-    const bool f64 = dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
-    {
+    if (nfft > 65536) return fail(c, SPEC_EUNSUPPORTED, "Welch PSD: nfft = %u is not supported (1 ... 65536)", nfft);
+    const bool f64 = out_f64 || dt == SPEC_DT_CF64_LE || dt == SPEC_DT_CF64_BE;
+    // lengths the FFT kernels have a plan for; everything else (not a power of two, or nfft = 1) is a plain DFT
+    bool pow2 = (nfft & (nfft - 1)) == 0;
+    const int log2n = pow2 ? ilog2(nfft) : 0;
+    if (pow2) {
         int l1 = 0, l2 = 0;
-        if (!plan_supported(log2n, f64) && !large_split(log2n, f64, &l1, &l2))
-            return fail(c, SPEC_EUNSUPPORTED, "Welch PSD: nfft = %u is not supported (2 ... 65536)", nfft);
+        pow2 = plan_supported(log2n, f64) || large_split(log2n, f64, &l1, &l2);
     }
-    HIP_TRY(c, hipSetDevice(c->device));
+    spec_status st = SPEC_OK;
+    float *psd_out = static_cast<float *>(psd_out_v);  // the fused fp32 path (never taken with out_f64)
+    const size_t out_esz = out_f64 ? 8 : 4;
     const uint64_t bps = spec_bytes_per_sample(dt);
-    const uint64_t span = ((uint64_t)(n_seg - 1) * hop + nfft) * bps;
-    const uint64_t total = (uint64_t)(n_psd - 1) * psd_stride_bytes + span;
+    uint64_t span = 0, total = 0;
+    if (!mul_add_u64((uint64_t)(n_seg - 1) * hop + nfft, bps, 0, &span) ||
+        !mul_add_u64((uint64_t)(n_psd - 1), psd_stride_bytes, span, &total))
+        return fail(c, SPEC_ERANGE, "Welch PSD: %u PSDs x %u segments do not fit a 64-bit byte count", n_psd, n_seg);
     if (start_byte > n_bytes || total > n_bytes - start_byte)
         return fail(c, SPEC_ERANGE, "Welch PSD needs bytes [%llu, +%llu) of %llu", (unsigned long long)start_byte,
                     (unsigned long long)total, (unsigned long long)n_bytes);
@@ -746,6 +917,33 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
                                   hipMemcpyHostToDevice, c->stream));
         d_in = static_cast<const uint8_t *>(c->stage_in);
     }
+    if (!pow2) {
+        // plain fp64 DFT with the exact W_N table (spec_misc.hip welch_dft_kernel)
+        const void *twn = nullptr, *winn = nullptr;
+        double s1 = 0, s2 = 0;
+        st = get_tables_n(c, nfft, window, &twn, &winn, &s1, &s2);
+        if (st != SPEC_OK) return st;
+        if (!(s2 > 0)) return fail(c, SPEC_EINVAL, "the window of %u point(s) sums to zero", nfft);
+        void *d_out = psd_out_v;
+        if (!out_on_device) {
+            st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * out_esz);
+            if (st != SPEC_OK) return st;
+            d_out = c->stage_out;
+        }
+        const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
+        hipError_t e = launch_welch_dft(d_in, psd_stride_bytes, n_psd, n_seg, hop, (uint32_t)bps, kind_of(dt, c->flags),
+                                        is_be(dt), nfft, twn, winn, norm, db, d_out, out_f64, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch DFT launch: %s", hipGetErrorString(e));
+        if (!out_on_device) {
+            HIP_TRY(c, hipMemcpyAsync(psd_out_v, d_out, (size_t)n_psd * nfft * out_esz, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else if (!iq_on_device) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (freq_out)
+            for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
+        return SPEC_OK;
+    }
     WelchArgs a{};
     a.iq = d_in;
     a.psd_stride_bytes = psd_stride_bytes;
@@ -760,7 +958,7 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
     double s1 = 0, s2 = 0;
     st = get_window(c, log2n, false, window, &a.win, &s1, &s2);
     if (st != SPEC_OK) return st;
-    if (!c->opt_force_generic && v2_applicable(log2n, a.kind, a.be, OUT_POW_F32, n_seg, hop)) {
+    if (!out_f64 && !c->opt_force_generic && v2_applicable(log2n, a.kind, a.be, OUT_POW_F32, n_seg, hop)) {
         // packed-fp32 family: sub-lines accumulate |X|^2 over runs of segments, one slab each
         st = get_window(c, log2n, false, window, &a.win, &s1, &s2, /*table_for_rect=*/true);
         if (st != SPEC_OK) return st;
@@ -808,11 +1006,11 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
     st = grow(c, &c->scratch2, &c->scratch2_bytes, (size_t)seg_chunk * nfft * esz + (size_t)nfft * sizeof(double));
     if (st != SPEC_OK) return st;
     double *acc = reinterpret_cast<double *>(static_cast<uint8_t *>(c->scratch2) + (size_t)seg_chunk * nfft * esz);
-    float *d_out = psd_out;
+    uint8_t *d_out = static_cast<uint8_t *>(psd_out_v);
     if (!out_on_device) {
-        st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * sizeof(float));
+        st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * out_esz);
         if (st != SPEC_OK) return st;
-        d_out = static_cast<float *>(c->stage_out);
+        d_out = static_cast<uint8_t *>(c->stage_out);
     }
     st = get_window(c, log2n, f64, window, &a.win, &s1, &s2);
     if (st != SPEC_OK) return st;
@@ -827,11 +1025,11 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
             hipError_t e = launch_welch_accum(c->scratch2, f64, ns, nfft, acc, c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch accumulate launch: %s", hipGetErrorString(e));
         }
-        hipError_t e = launch_welch_scale(acc, nfft, norm, db, d_out + (size_t)b * nfft, c->stream);
+        hipError_t e = launch_welch_scale(acc, nfft, norm, db, d_out + (size_t)b * nfft * out_esz, out_f64, c->stream);
         if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch scale launch: %s", hipGetErrorString(e));
     }
     if (!out_on_device) {
-        HIP_TRY(c, hipMemcpyAsync(psd_out, d_out, (size_t)n_psd * nfft * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(psd_out_v, d_out, (size_t)n_psd * nfft * out_esz, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     } else if (!iq_on_device) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // staging buffer may be reused by the next call
@@ -841,23 +1039,32 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
     return SPEC_OK;
 }
 
+spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
+                           uint64_t psd_stride_bytes, uint32_t n_psd, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                           uint32_t n_seg, spec_window window, spec_psd_scaling scaling, double fs, int db,
+                           double *freq_out, float *psd_out, int out_on_device) {
+    return welch_impl(c, iq, iq_on_device, n_bytes, start_byte, psd_stride_bytes, n_psd, dt, nfft, hop, n_seg, window, scaling,
+                      fs, db, freq_out, psd_out, out_on_device, false);
+}
+
 // Exact shape of the call at AnalysisDialogController.java:308-312:
 //   PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft)
 // with data[0] = I, data[1] = Q (planar doubles, the output of the down-converter).
 spec_status spec_welch_psd_planar_f64(spec_ctx *c, const double *re, const double *im, int in_on_device,
                                       uint64_t n_samples, uint32_t nfft, uint32_t hop, spec_window window,
-                                      spec_psd_scaling scaling, double fs, int db, double *freq_out, float *psd_out) {
+                                      spec_psd_scaling scaling, double fs, int db, double *freq_out, double *psd_out) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!re || !im || !psd_out) return fail(c, SPEC_EINVAL, "null buffer");
-    if (nfft == 0 || (nfft & (nfft - 1)) != 0) return fail(c, SPEC_EINVAL, "nfft = %u is not a power of two", nfft);
+    if (nfft == 0) return fail(c, SPEC_EINVAL, "nfft must be >= 1");
     if (hop == 0) return fail(c, SPEC_EINVAL, "hop must be >= 1");
     if (n_samples < nfft) return fail(c, SPEC_ERANGE, "signal of %llu samples is shorter than nfft = %u",
                                       (unsigned long long)n_samples, nfft);
     const uint64_t n_seg = (n_samples - nfft) / hop + 1, used = (n_seg - 1) * hop + nfft;
     if (n_seg > 0xFFFFFFFFull) return fail(c, SPEC_EINVAL, "too many segments");
+    if (used > (1ull << 40)) return fail(c, SPEC_ERANGE, "signal of %llu samples is out of range", (unsigned long long)used);
     // the two planes go up as they are and are interleaved on the device (a host loop over 2 x 20 M doubles
     // cost 90 of the call's 99 ms)
-    HIP_TRY(c, hipSetDevice(c->device));
     spec_status st = grow(c, &c->planar, &c->planar_bytes, 2 * used * sizeof(double));
     if (st != SPEC_OK) return st;
     const double *d_re = re, *d_im = im;
@@ -872,19 +1079,21 @@ spec_status spec_welch_psd_planar_f64(spec_ctx *c, const double *re, const doubl
     }
     hipError_t e = launch_interleave(d_re, d_im, c->planar, used, c->stream);
     if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "interleave launch: %s", hipGetErrorString(e));
-    return spec_welch_psd(c, c->planar, 1, used * 16, 0, 0, 1, SPEC_DT_CF64_LE, nfft, hop, (uint32_t)n_seg, window, scaling, fs,
-                          db, freq_out, psd_out, 0);
+    return welch_impl(c, c->planar, 1, used * 16, 0, 0, 1, SPEC_DT_CF64_LE, nfft, hop, (uint32_t)n_seg, window, scaling, fs,
+                      db, freq_out, psd_out, 0, true);
 }
 
 spec_status spec_render_spectrogram(spec_ctx *c, const float *tile, int tile_on_device, uint32_t width,
                                     uint32_t nfft, uint32_t height, double fs, double min_db, double max_db,
                                     spec_colormap colormap, void *bgra_out, int out_on_device) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!tile || !bgra_out) return fail(c, SPEC_EINVAL, "null buffer");
     if (nfft == 0 || !(fs > 0)) return fail(c, SPEC_EINVAL, "nfft and fs must be positive");
     if (colormap != SPEC_CMAP_GRAYSCALE && colormap != SPEC_CMAP_HEATMAP) return fail(c, SPEC_EINVAL, "bad colormap");
     if (width == 0 || height == 0) return SPEC_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (nfft > (1u << 24) || height > (1u << 20) || width > (1u << 24))
+        return fail(c, SPEC_ERANGE, "image of %u x %u pixels over %u bins is out of range", width, height, nfft);
     const size_t in_bytes = (size_t)width * nfft * sizeof(float), out_bytes = (size_t)width * height * 4;
     const float *d_tile = tile;
     if (!tile_on_device) {
@@ -916,9 +1125,9 @@ spec_status spec_waterfall_render(spec_ctx *c, const void *iq, int iq_on_device,
                                   uint32_t n_lines, spec_window window, uint32_t height, double fs, double min_db,
                                   double max_db, spec_colormap colormap, void *bgra_out, int out_on_device) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!bgra_out) return fail(c, SPEC_EINVAL, "null buffer");
     if (n_lines == 0 || height == 0) return SPEC_OK;
-    HIP_TRY(c, hipSetDevice(c->device));
     // Fused form: the image samples ONE bin per pixel row (MC:1280), so the FFT kernel stores only those
     // `height` bins of every line (a compact [n_lines][height] tile) and the colour kernel reads that.
     // Needs a kernel of the packed family with 16-point threads and a one-to-one bin -> row map.
@@ -992,15 +1201,29 @@ static void edc_layout(const spec_ctx *c, spec_dtype dt, int *kind, uint32_t *st
     }
 }
 
+// the range test alone (no staging, no launch): entry points run it before they size anything from `count`
+static spec_status burst_check(spec_ctx *c, uint64_t capacity, uint64_t start_sample, uint64_t count, spec_dtype dt) {
+    int kind; uint32_t stride, width;
+    edc_layout(c, dt, &kind, &stride, &width);
+    uint64_t start_byte = 0, span = 0;
+    if (count == 0 || !mul_add_u64(start_sample, stride, 0, &start_byte) || !mul_add_u64(count - 1, stride, width, &span) ||
+        start_byte > capacity || span > capacity - start_byte)
+        return fail(c, SPEC_ERANGE, "samples [%llu, +%llu) leave the %llu-byte buffer", (unsigned long long)start_sample,
+                    (unsigned long long)count, (unsigned long long)capacity);
+    return SPEC_OK;
+}
+
 // range-check the burst and make its raw bytes device-resident: *d_raw points at sample start_sample
 static spec_status burst_locate(spec_ctx *c, const void *buffer, int on_device, uint64_t capacity, uint64_t start_sample,
                                 uint64_t count, spec_dtype dt, const uint8_t **d_raw, int *kind, uint32_t *stride) {
     uint32_t width;
     edc_layout(c, dt, kind, stride, &width);
-    const uint64_t start_byte = start_sample * *stride, span = (count - 1) * *stride + width;
-    if (start_sample > capacity / *stride || start_byte + span > capacity)
-        return fail(c, SPEC_ERANGE, "samples [%llu, %llu) leave the %llu-byte buffer", (unsigned long long)start_sample,
-                    (unsigned long long)(start_sample + count), (unsigned long long)capacity);
+    // phrased without wrap-around: a huge count must be SPEC_ERANGE, never a launch
+    uint64_t start_byte = 0, span = 0;
+    if (count == 0 || !mul_add_u64(start_sample, *stride, 0, &start_byte) || !mul_add_u64(count - 1, *stride, width, &span) ||
+        start_byte > capacity || span > capacity - start_byte)
+        return fail(c, SPEC_ERANGE, "samples [%llu, +%llu) leave the %llu-byte buffer", (unsigned long long)start_sample,
+                    (unsigned long long)count, (unsigned long long)capacity);
     if (on_device) {
         *d_raw = static_cast<const uint8_t *>(buffer) + start_byte;
         if (reinterpret_cast<uintptr_t>(*d_raw) % component_bytes(dt) != 0)
@@ -1030,10 +1253,14 @@ spec_status spec_extract_iq(spec_ctx *c, const void *buffer, int buffer_on_devic
                             uint64_t start_sample, uint64_t count, spec_dtype dt, double *re, double *im,
                             int out_on_device) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!dtype_valid(dt)) return fail(c, SPEC_EINVAL, "bad datatype %d", (int)dt);
     if (count == 0) return SPEC_OK;
     if (!buffer || !re || !im) return fail(c, SPEC_EINVAL, "null buffer");
-    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        spec_status rst = burst_check(c, capacity, start_sample, count, dt);
+        if (rst != SPEC_OK) return rst;
+    }
     double *d_re = re, *d_im = im;
     if (!out_on_device) {
         spec_status st = grow(c, &c->stage_out, &c->stage_out_bytes, 2 * count * sizeof(double));
@@ -1055,6 +1282,7 @@ spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_dev
                               uint64_t start_sample, uint64_t count, spec_dtype dt, double freq_off, uint32_t down,
                               spec_downconv_mode mode, double *re_out, double *im_out, int out_on_device) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!dtype_valid(dt)) return fail(c, SPEC_EINVAL, "bad datatype %d", (int)dt);
     if (down == 0 || down > (1u << 20)) return fail(c, SPEC_EINVAL, "down = %u out of range", down);
     if (mode != SPEC_DC_FAST && mode != SPEC_DC_LPF) return fail(c, SPEC_EINVAL, "bad mode %d", (int)mode);
@@ -1062,7 +1290,10 @@ spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_dev
     const uint64_t n_out = count / down;
     if (n_out == 0) return SPEC_OK;
     if (!buffer || !re_out || !im_out) return fail(c, SPEC_EINVAL, "null buffer");
-    HIP_TRY(c, hipSetDevice(c->device));
+    {
+        spec_status rst = burst_check(c, capacity, start_sample, count, dt);
+        if (rst != SPEC_OK) return rst;
+    }
     double *d_or = re_out, *d_oi = im_out;
     if (!out_on_device) {
         spec_status st = grow(c, &c->stage_out, &c->stage_out_bytes, 2 * n_out * sizeof(double));
@@ -1125,11 +1356,12 @@ spec_status spec_down_convert(spec_ctx *c, const void *buffer, int buffer_on_dev
 static spec_status run_trace(spec_ctx *c, int kind_trace, const double *re, const double *im, int in_on_device,
                              uint64_t n, double alpha, double fs, double add, double *out, int out_on_device) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     const uint64_t n_out = kind_trace == 0 ? n : (n > 0 ? n - 1 : 0);
     if (n_out == 0) return SPEC_OK;
     if (!re || !im || !out) return fail(c, SPEC_EINVAL, "null buffer");
     if (std::isnan(alpha)) return fail(c, SPEC_EINVAL, "alpha is NaN");
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > (1ull << 40)) return fail(c, SPEC_ERANGE, "trace of %llu samples is out of range", (unsigned long long)n);
     const double *d_re = re, *d_im = im;
     if (!in_on_device) {
         spec_status st = grow(c, &c->stage_in, &c->stage_in_bytes, 2 * n * sizeof(double));
@@ -1168,9 +1400,9 @@ spec_status spec_inst_freq_trace(spec_ctx *c, const double *re, const double *im
 spec_status spec_synth_iq(spec_ctx *c, void *dev_out, spec_dtype dt, uint64_t seed, uint64_t first_sample,
                           uint64_t n_samples) {
     if (!c) return SPEC_EINVAL;
+    Enter g(c);
     if (!dev_out) return fail(c, SPEC_EINVAL, "null buffer");
     if (!dtype_valid(dt) || dt == SPEC_DT_UNKNOWN) return fail(c, SPEC_EINVAL, "bad spec_dtype %d", dt);
-    HIP_TRY(c, hipSetDevice(c->device));
     hipError_t e = launch_synth(dev_out, kind_of(dt, 0), is_be(dt), seed, first_sample, n_samples, c->stream);
     if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "synth launch: %s", hipGetErrorString(e));
     return SPEC_OK;

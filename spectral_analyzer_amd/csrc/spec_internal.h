@@ -48,8 +48,19 @@ hipError_t launch_spectro_f64(const WfArgs &a, int log2n, hipStream_t s);
 // W_N1 / W_N2 tables of the split, scratch holds n_lines * N complex values
 bool large_split(int log2n, bool f64, int *l1, int *l2);
 size_t large_scratch_bytes_per_line(int log2n, bool f64);
+// run_if != nullptr: the kernels start only when *run_if != 0 (the fall-back behind the team kernel)
 hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2,
-                                void *scratch, hipStream_t s);
+                                void *scratch, hipStream_t s, const uint32_t *run_if = nullptr);
+// the same decomposition as ONE persistent launch with the intermediate kept in each XCD's L2 (spec_k_team.hip):
+// `sync` (large_team_sync_bytes(), zeroed on the stream before the call) carries the tickets and ring counters;
+// word large_team_abort_word() is non-zero afterwards when a bounded wait timed out (output incomplete).
+// query_only: report in *teams_max how many teams the launch can form at most (scratch = teams_max * ring * nfft
+// complex values) without launching.
+size_t large_team_sync_bytes();
+uint32_t large_team_abort_word();
+hipError_t launch_spectro_team(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2, void *scratch,
+                               uint32_t ring, uint32_t *sync, int n_cu, uint32_t *teams_max, bool query_only,
+                               hipStream_t s);
 
 // packed-fp32 family (spec_v2.h): every LDS-resident size, cf32/ci16/cu8/ci8 little endian
 bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, uint32_t hop);
@@ -69,7 +80,13 @@ hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t 
 // fallback Welch: acc[k] += sum over n lines of fftshifted power lines (float or double);
 // then scale / dB into psd_out
 hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint32_t nfft, double *acc, hipStream_t s);
-hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);
+hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, void *psd_out, int out_f64,
+                              hipStream_t s);
+// Welch PSD of any length by a plain fp64 DFT (non power-of-two nfft, ADC:303-307): tw = cx<double>[nfft] table
+// W_N^m, win = double[nfft] or nullptr; writes the scaled, fftshifted PSDs (float or double)
+hipError_t launch_welch_dft(const uint8_t *iq, uint64_t psd_stride_bytes, uint32_t n_psd, uint32_t n_seg, uint32_t hop,
+                            uint32_t bps, int kind, int be, uint32_t nfft, const void *tw, const void *win, double norm,
+                            int db, void *out, int out_f64, hipStream_t s);
 // compact != 0: tile is [width][height] with column f = the bin pixel row f samples (launch_v2_spectro_sel)
 hipError_t launch_render(const float *tile, uint32_t width, uint32_t nfft, uint32_t height, double conversion,
                          double min_db, double max_db, int colormap, int compact, void *bgra, hipStream_t s);

@@ -43,6 +43,7 @@ struct LargeArgs {
     void *scratch;                // cx<R>[n_lines][N], [n2][k1] order
     void *out;
     int out_fmt;
+    const uint32_t *run_if;       // nullptr, or: run only when *run_if != 0 (fall-back behind spec_k_team.hip)
 };
 
 // Both kernels walk TPW consecutive tiles per workgroup and request the next tile's operands before the
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(Plan<L1>::WG, 2) void large_cols_kernel(const Large
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cx<R> *lds = reinterpret_cast<cx<R> *>(smem);
     const int tid = threadIdx.x;
+    if (a.run_if && *a.run_if == 0) return;
     const int q0 = tid % LG::CA, t0 = tid / LG::CA;  // loads: columns fastest (contiguous samples)
     const int t1 = tid % PA::T, q1 = tid / PA::T;    // stores: k1 fastest (contiguous scratch)
     constexpr uint32_t TILES = LG::N2 / LG::CA;
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(Plan<L2>::WG, 2) void large_rows_kernel(const Large
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cx<R> *lds = reinterpret_cast<cx<R> *>(smem);
     const int tid = threadIdx.x;
+    if (a.run_if && *a.run_if == 0) return;
     const int q0 = tid % LG::CB, t0 = tid / LG::CB;  // rows k1 fastest: both the scratch reads and the final stores
     constexpr uint32_t TILES = LG::N1 / LG::CB;
     const uint32_t total = a.n_lines * TILES;
@@ -208,8 +211,9 @@ bool large_split(int log2n, bool f64, int *l1, int *l2) {
 size_t large_scratch_bytes_per_line(int log2n, bool f64) { return ((size_t)1 << log2n) * (f64 ? 16 : 8); }
 
 hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2,
-                                void *scratch, hipStream_t s) {
+                                void *scratch, hipStream_t s, const uint32_t *run_if) {
     LargeArgs a{};
+    a.run_if = run_if;
     a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.bps = w.bps; a.kind = w.kind; a.be = w.be;
     a.tw1 = tw1; a.tw2 = tw2; a.twn = w.tw; a.win = w.win; a.scratch = scratch; a.out = w.out; a.out_fmt = w.out_fmt;
     if (f64) {

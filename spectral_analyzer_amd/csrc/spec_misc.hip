@@ -82,11 +82,12 @@ __global__ __launch_bounds__(256) void welch_accum_kernel(const T *__restrict__ 
     }
 }
 __global__ void welch_scale_kernel(const double *__restrict__ acc, uint32_t nfft, double norm, int db,
-                                   float *__restrict__ out) {
+                                   void *__restrict__ out, int out_f64) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nfft) return;
-    const double v = acc[k] * norm;
-    out[k] = db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+    const double v = acc[k] * norm, r = db ? 10.0 * log10(v + 1e-20) : v;
+    if (out_f64) static_cast<double *>(out)[k] = r;
+    else static_cast<float *>(out)[k] = (float)r;
 }
 hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint32_t nfft, double *acc, hipStream_t s) {
     if (lines_f64) hipLaunchKernelGGL(welch_accum_kernel<double>, dim3((nfft + 31) / 32), dim3(256), 0, s,
@@ -95,8 +96,73 @@ hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint
                             static_cast<const float *>(lines), n, nfft, acc);
     return hipGetLastError();
 }
-hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s) {
-    hipLaunchKernelGGL(welch_scale_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, acc, nfft, norm, db, psd_out);
+hipError_t launch_welch_scale(const double *acc, uint32_t nfft, double norm, int db, void *psd_out, int out_f64,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(welch_scale_kernel, dim3((nfft + 255) / 256), dim3(256), 0, s, acc, nfft, norm, db, psd_out, out_f64);
+    return hipGetLastError();
+}
+
+// ---- Welch PSD of an arbitrary (non power-of-two) length: plain DFT in fp64 -------------------------
+// AnalysisDialogController.java:303-307 hands calculatePsdWelch the burst length itself whenever the
+// down-converted burst is shorter than 8192 samples -- any integer, one segment.  X[k] = sum_n x[n] w[n]
+// W_N^(nk mod N) with the exact table W_N^m (long double on the host, rounded once) and the index kept
+// by modular addition, so the only error is the fp64 summation (~sqrt(N) eps).  One thread per bin k; the
+// segment's decoded, windowed samples pass through LDS 256 at a time.  O(N^2) per segment: meant for the
+// dialog's short bursts (N <= 8191: 67 M complex multiply-adds), correct for any N the table fits.
+__global__ __launch_bounds__(256) void welch_dft_kernel(const uint8_t *__restrict__ iq, uint64_t psd_stride_bytes,
+                                                        uint32_t n_seg, uint32_t hop, uint32_t bps, int kind, int be,
+                                                        uint32_t N, const cx<double> *__restrict__ tw,
+                                                        const double *__restrict__ win, double norm, int db, void *out,
+                                                        int out_f64) {
+    __shared__ cx<double> xs[256];
+    const uint32_t tid = threadIdx.x, k = blockIdx.x * 256 + tid, psd = blockIdx.y;
+    const uint8_t *base = iq + (uint64_t)psd * psd_stride_bytes;
+    double acc = 0.0;
+    for (uint32_t seg = 0; seg < n_seg; ++seg) {
+        const uint8_t *sb = base + (uint64_t)seg * hop * bps;
+        double ar = 0.0, ai = 0.0;
+        uint32_t m = 0;  // (n k) mod N
+        for (uint32_t n0 = 0; n0 < N; n0 += 256) {
+            __syncthreads();
+            if (n0 + tid < N) {
+                cx<double> x = decode_sample<double>(sb + (uint64_t)(n0 + tid) * bps, kind, be != 0);
+                if (win) { const double w = win[n0 + tid]; x.x *= w; x.y *= w; }
+                xs[tid] = x;
+            }
+            __syncthreads();
+            const uint32_t cnt = N - n0 < 256 ? N - n0 : 256;
+            if (k < N) {
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const cx<double> w = tw[m], x = xs[j];
+                    ar += x.x * w.x - x.y * w.y;
+                    ai += x.x * w.y + x.y * w.x;
+                    m += k;
+                    if (m >= N) m -= N;
+                }
+            }
+        }
+        acc += ar * ar + ai * ai;
+    }
+    if (k < N) {
+        const double v = acc * norm;
+        const double r = db ? 10.0 * log10(v + 1e-20) : v;
+        const uint64_t o = (uint64_t)psd * N + (k + N / 2) % N;  // numpy.fft.fftshift for odd N too
+        if (out_f64) static_cast<double *>(out)[o] = r;
+        else static_cast<float *>(out)[o] = (float)r;
+    }
+}
+
+hipError_t launch_welch_dft(const uint8_t *iq, uint64_t psd_stride_bytes, uint32_t n_psd, uint32_t n_seg, uint32_t hop,
+                            uint32_t bps, int kind, int be, uint32_t nfft, const void *tw, const void *win, double norm,
+                            int db, void *out, int out_f64, hipStream_t s) {
+    const size_t esz = out_f64 ? 8 : 4;
+    for (uint32_t p0 = 0; p0 < n_psd; p0 += 65535) {  // grid.y limit
+        const uint32_t np = n_psd - p0 < 65535 ? n_psd - p0 : 65535;
+        hipLaunchKernelGGL(welch_dft_kernel, dim3((nfft + 255) / 256, np), dim3(256), 0, s,
+                           iq + (uint64_t)p0 * psd_stride_bytes, psd_stride_bytes, n_seg, hop, bps, kind, be, nfft,
+                           static_cast<const cx<double> *>(tw), static_cast<const double *>(win), norm, db,
+                           static_cast<uint8_t *>(out) + (uint64_t)p0 * nfft * esz, out_f64);
+    }
     return hipGetLastError();
 }
 

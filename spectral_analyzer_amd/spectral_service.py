@@ -228,7 +228,7 @@ class SpectralService:
         """Welch PSD; returns ``(freq[nfft], psd[n_psd, nfft])`` like the two
         rows the reference plots (ADC:324-328).  ``hop`` defaults to nfft/2 and
         ``n_seg`` to every whole segment available after ``start_byte``."""
-        hop = int(nfft // 2 if hop is None else hop)
+        hop = int(max(nfft // 2, 1) if hop is None else hop)
         dt = dtype_from_sigmf(datatype)
         on_dev = _is_torch(buffer)
         n_bytes = buffer.numel() if on_dev else None
@@ -259,17 +259,19 @@ class SpectralService:
                             window: int = L.WIN_HANN, scaling: int = L.PSD_DENSITY, db: bool = False):
         """The call at ADC:308-312, ``PowerSpectralDensity.calculatePsdWelch(data, fs, nfft)``:
         ``data`` is ``double[2][N]`` (row 0 = I, row 1 = Q); returns ``[freq, psd]`` like the
-        reference's two rows.  Window / overlap / scaling are explicit because JDSP's are not
-        known (defaults: Hann, 50 %, density, linear)."""
+        reference's two rows (doubles, fp64 pipeline).  ``nfft`` is any integer >= 1: the dialog
+        passes the burst length for bursts shorter than 8192 samples (ADC:303-307).  Window /
+        overlap / scaling are explicit because JDSP's are not known (defaults: Hann, 50 %,
+        density, linear)."""
         keep, pre, pim, n, dev = self._planar(data)  # host double[2][N] or a device tensor (the down-converter's)
-        hop = int(nfft // 2 if hop is None else hop)
+        hop = int(max(nfft // 2, 1) if hop is None else hop)
         freq = np.empty(max(int(nfft), 0), dtype=np.float64)
-        psd = np.empty(max(int(nfft), 0), dtype=np.float32)
+        psd = np.empty(max(int(nfft), 0), dtype=np.float64)
         self._check(self._lib.spec_welch_psd_planar_f64(
             self._ctx, pre, pim, dev, n, int(nfft) & 0xFFFFFFFF, hop, window,
             scaling, float(fs), int(db), freq.ctypes.data, psd.ctypes.data))
         del keep
-        return np.stack([freq, psd.astype(np.float64)])
+        return np.stack([freq, psd])
 
     # -- Analysis dialog traces (ADC:219-284) --------------------------------
     def _planar(self, data):

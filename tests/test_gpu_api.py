@@ -327,7 +327,110 @@ def test_calculate_psd_welch_call_shape(svc, oracle):
     with pytest.raises(IndexError):                      # shorter than nfft: the caller picks nfft (ADC:303-307)
         svc.calculate_psd_welch(data[:, :100], fs, nfft)
     with pytest.raises(ValueError):
-        svc.calculate_psd_welch(data, fs, 1000)
+        svc.calculate_psd_welch(data, fs, 0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 1000, 4097, 8191])
+def test_welch_any_length(svc, oracle, n):
+    """ADC:303-307: a burst shorter than 8192 samples is handed to calculatePsdWelch with
+    nfft = data[0].length -- any integer.  Plain fp64 DFT on the device; checked against the oracle's
+    O(N^2) DFT and against numpy.fft.fft, <= 1e-9 of the peak (doubles out)."""
+    rng = np.random.default_rng(n)
+    fs = 48e3
+    x = rng.normal(size=n) + 1j * rng.normal(size=n) + 2 * np.exp(2j * np.pi * 0.2 * np.arange(n))
+    data = np.stack([x.real, x.imag])
+    window = sa.WIN_RECT if n == 1 else sa.WIN_HANN          # a one-point Hann window is 0
+    out = svc.calculate_psd_welch(data, fs, n, window=window)
+    assert out.shape == (2, n) and out.dtype == np.float64
+    iq = np.ascontiguousarray(data.T).astype("<f8").tobytes()
+    f_ref, p_ref = oracle.welch_psd(np.frombuffer(iq, np.uint8), 0, "cf64_le", n, max(n // 2, 1), 1, window,
+                                    oracle.PSD_DENSITY, fs)
+    w = np.ones(n) if window == sa.WIN_RECT else 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)
+    p_np = np.fft.fftshift(np.abs(np.fft.fft(x * w)) ** 2 / (fs * np.sum(w * w)))
+    assert np.array_equal(out[0], f_ref) and np.allclose(out[0], np.fft.fftshift(np.fft.fftfreq(n, 1 / fs)), atol=1e-9)
+    assert np.abs(out[1] - p_ref).max() <= 1e-9 * p_ref.max()
+    assert np.abs(out[1] - p_np).max() <= 1e-9 * p_np.max()
+    if n == 1:
+        with pytest.raises(ValueError):                      # Hann of one point sums to zero
+            svc.calculate_psd_welch(data, fs, 1)
+
+
+def test_welch_any_length_raw_bytes_and_segments(svc, oracle):
+    # the batched entry over raw recording bytes takes the same lengths: several segments, two PSDs, floats out
+    dt, nfft, hop, n_seg, fs = "ci16_le", 1500, 700, 4, 1e6
+    per = (n_seg - 1) * hop + nfft
+    iq = oracle.synth_iq(dt, 21, 0, 2 * per)
+    f, p = svc.welch_psd(iq, 0, dt, fs, nfft=nfft, hop=hop, n_seg=n_seg, n_psd=2, psd_stride_bytes=per * 4)
+    for b in range(2):
+        f_ref, ref = oracle.welch_psd(iq, b * per * 4, dt, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY, fs)
+        assert np.array_equal(f, f_ref) and np.abs(p[b] - ref).max() <= 1e-6 * ref.max()
+    with pytest.raises(NotImplementedError):
+        svc.welch_psd(iq, 0, dt, fs, nfft=65537, hop=1, n_seg=1)
+
+
+def test_context_shared_by_threads(svc, oracle):
+    """AsyncExtractDownConvertService.java:27-35,52-55 runs the singleton on a pool of availableProcessors()
+    threads: eight host threads on ONE context give the serial results."""
+    import threading
+    edc = sa.ExtractDownConvertService(svc)
+    raw = oracle.synth_iq("ci16_le", 77, 0, 300000)
+    jobs = [(1000 * i, 40000 + 1111 * i, 0.01 * (i + 1), 4 + i, bool(i & 1)) for i in range(8)]
+    serial = [edc.extract_and_down_convert(raw, s0, cnt, "ci16_le", f, d, fast) for (s0, cnt, f, d, fast) in jobs]
+    lines = [svc.compute_magnitudes(raw, 4 * 1024 * i, 1024, "ci16_le") for i in range(8)]
+    got, got_lines, errors = [None] * 8, [None] * 8, []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                s0, cnt, f, d, fast = jobs[i]
+                got[i] = edc.extract_and_down_convert(raw, s0, cnt, "ci16_le", f, d, fast)
+                got_lines[i] = svc.compute_magnitudes(raw, 4 * 1024 * i, 1024, "ci16_le")
+        except Exception as e:                               # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for i in range(8):
+        assert np.array_equal(got[i], serial[i]) and np.array_equal(got_lines[i], lines[i])
+
+
+def test_huge_counts_are_rejected_before_any_launch(svc):
+    """Range checks must not wrap: counts near 2^64 are SPEC_ERANGE / SPEC_EINVAL, never a launch."""
+    import ctypes as C
+    import torch
+    from spectral_analyzer_amd import _lib as L
+    lib, ctx = L.load(), svc._ctx
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    big = 2 ** 64 - 1
+    p, o = buf.data_ptr(), out.data_ptr()
+    assert lib.spec_extract_iq(ctx, p, 1, 4096, 1, big, L.DT_CI16_LE, o, o, 1) == L.SPEC_ERANGE
+    assert lib.spec_extract_iq(ctx, p, 1, 4096, big, 2, L.DT_CI16_LE, o, o, 1) == L.SPEC_ERANGE
+    assert lib.spec_extract_iq(ctx, p, 1, 4096, 2 ** 62, 2 ** 62, L.DT_CF64_LE, o, o, 1) == L.SPEC_ERANGE
+    assert lib.spec_down_convert(ctx, p, 1, 4096, 1, big, L.DT_CI16_LE, 0.1, 2, 0, o, o, 1) == L.SPEC_ERANGE
+    assert lib.spec_down_convert(ctx, p, 1, 4096, 1, big - 7, L.DT_CF32_LE, 0.1, 3, 1, o, o, 1) == L.SPEC_ERANGE
+    assert lib.spec_magnitude_trace(ctx, o, o, 1, big // 8, 0.5, o, 1) == L.SPEC_ERANGE
+    assert lib.spec_inst_freq_trace(ctx, o, o, 1, 2 ** 61, 0.5, 1.0, 0.0, o, 1) == L.SPEC_ERANGE
+    f32 = torch.zeros(1024, dtype=torch.float32, device="cuda")
+    assert lib.spec_welch_psd(ctx, p, 1, 4096, 0, big // 2, 2 ** 32 - 1, L.DT_CF32_LE, 64, 2 ** 32 - 1, 2 ** 32 - 1,
+                              L.WIN_HANN, L.PSD_DENSITY, 1.0, 0, None, f32.data_ptr(), 1) == L.SPEC_ERANGE
+    assert lib.spec_welch_psd(ctx, p, 1, 4096, 0, 16, 3, L.DT_CF32_LE, 64, 2 ** 32 - 1, 2 ** 32 - 1,
+                              L.WIN_HANN, L.PSD_DENSITY, 1.0, 0, None, f32.data_ptr(), 1) == L.SPEC_ERANGE
+    assert lib.spec_waterfall(ctx, p, 1, 4096, 0, L.DT_CF32_LE, 64, 64, big, L.WIN_RECT, L.OUT_DB20_F32, -150.0,
+                              f32.data_ptr(), 1) == L.SPEC_ERANGE
+    assert lib.spec_welch_psd_planar_f64(ctx, o, o, 1, 2 ** 63, 64, 1, L.WIN_HANN, L.PSD_DENSITY, 1.0, 0, None,
+                                         o) in (L.SPEC_ERANGE, L.SPEC_EINVAL)
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0 and float(f32.abs().sum()) == 0.0     # nothing was written
+
+
+def test_calls_leave_the_current_device_alone(svc):
+    import torch
+    before = torch.cuda.current_device()
+    svc.compute_magnitudes(np.zeros(8 * 64, np.uint8), 0, 64, "cf32_le")
+    assert torch.cuda.current_device() == before
 
 
 # ---- SURVEY 8(f) next #1: renderSpectrogram + getColorForMagnitude (MC:1261-1291, MC:926-957) ------
