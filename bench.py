@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- spectrogram lines/s on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3 [--workload cfg2|cfg3|cfg4|cfg5|cfg1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (IQ bytes resident in HBM -> fftshifted
-20 log10|X| lines in HBM) over the rank's shard of the synthetic recording.
-Workload at N = 1 is BASELINE config 2: 4096-pt FFT, 50 % overlap, cf32,
-2^30 samples (524 287 lines).  With N > 1 every rank holds 2^30 samples of an
-N * 2^30-sample recording (time-slice sharding, weak scaling, no collective in
-the timed region -- lines are independent).
+A "step" is one pass of the hot path (IQ bytes resident in HBM -> results in HBM) over the rank's
+shard of the synthetic recording.  Workloads (BASELINE.json configs):
+  cfg2  4096-pt FFT, 50 % overlap, cf32, 2^30 samples (524 287 lines) -- the metric's config, default at N = 1
+  cfg3  4096-pt, ci16 (on-GPU int16 -> float), 2^30 samples per GPU = the per-GPU share of the 8 G-sample
+        recording -- default at N > 1, with the tile gather timed beside the compute-only figure
+  cfg4  Welch PSD, 16384-pt, Hann, 75 % overlap, 256 segments per PSD, cf32; 1024 independent PSDs per step
+        (one annotation each); a "line" is one segment; VALU-bound, so the roofline is the fp32 vector peak
+  cfg5  65536-pt FFT, cf64 -> f64 (the whole pipeline in fp64), 2^30 samples per GPU (32 767 lines)
+  cfg1  1024-pt, 1 M samples: the reference's own CPU-runnable case (2 047 lines: launch-bound)
+With N > 1 every rank holds its own 2^30 samples of an N * 2^30-sample recording (time-slice sharding,
+weak scaling; lines are independent, SURVEY 8e, so `value` has no collective in its timed region).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     -- algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (restated reference) timed on the host cores
+  roofline     -- algorithmic bytes (or flops) / HIP-event kernel time vs the peak that bounds the kernel
+  cpu_baseline -- the CPU oracle (restated reference) timed on the host cores: all cores, and ONE thread
+                  (the reference computes on the single JavaFX thread)
+  gather       -- N > 1 only: the same step with every rank's tile sent to rank 0 in chunks on a second
+                  stream while the next chunk is computed: compute+gather lines/s
 """
 from __future__ import annotations
 
@@ -32,16 +40,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (datatype, nfft, hop, log2 samples per GPU, window)
-    "cfg2": ("cf32_le", 4096, 2048, 30, 0),   # BASELINE configs[1] -- the metric's config
-    "cfg3": ("ci16_le", 4096, 2048, 30, 0),   # BASELINE configs[2] per-GPU share (8 G samples / 8)
-    "cfg1": ("cf32_le", 1024, 512, 20, 0),    # BASELINE configs[0] sizes (plumbing case)
+    # spectrogram: datatype, nfft, hop, log2 samples per GPU, window, output
+    "cfg2": dict(kind="spectro", datatype="cf32_le", nfft=4096, hop=2048, log2s=30, window=0, out="f32"),
+    "cfg3": dict(kind="spectro", datatype="ci16_le", nfft=4096, hop=2048, log2s=30, window=0, out="f32"),
+    "cfg1": dict(kind="spectro", datatype="cf32_le", nfft=1024, hop=512, log2s=20, window=0, out="f32"),
+    "cfg5": dict(kind="spectro", datatype="cf64_le", nfft=65536, hop=32768, log2s=30, window=0, out="f64"),
+    # Welch: n_psd independent PSDs of n_seg segments each, per GPU
+    "cfg4": dict(kind="welch", datatype="cf32_le", nfft=16384, hop=4096, n_seg=256, n_psd=1024, window=1),
     # development workloads (tools/ablate.sh): other line lengths at 50 % overlap
-    "n1024": ("cf32_le", 1024, 512, 30, 0),
-    "n8192": ("cf32_le", 8192, 4096, 30, 0),
-    "n16384": ("cf32_le", 16384, 8192, 30, 0),
+    "n1024": dict(kind="spectro", datatype="cf32_le", nfft=1024, hop=512, log2s=30, window=0, out="f32"),
+    "n8192": dict(kind="spectro", datatype="cf32_le", nfft=8192, hop=4096, log2s=30, window=0, out="f32"),
+    "n16384": dict(kind="spectro", datatype="cf32_le", nfft=16384, hop=8192, log2s=30, window=0, out="f32"),
+    "n65536f": dict(kind="spectro", datatype="cf32_le", nfft=65536, hop=32768, log2s=30, window=0, out="f32"),
 }
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 SEED = 0x5EC7A11A
 
 
@@ -57,15 +70,35 @@ def usable_cores() -> int:
     return n
 
 
+def cpu_baseline_for(so, host: np.ndarray, datatype: str, nfft: int, hop: int, window: int, lines_all: int,
+                     lines_one: int, what: str):
+    """The fp64 C oracle (= restated SpectralService.computeMagnitudes, SS:33-85) over the first lines of the
+    same recording: every usable core (pthreads over lines) and ONE thread (the reference's FX thread)."""
+    cores = usable_cores()
+    secs, _ = so.time_waterfall(host, datatype, nfft, hop, lines_all, window, cores)
+    secs1, _ = so.time_waterfall(host, datatype, nfft, hop, lines_one, window, 1)
+    return {"value": lines_all / secs, "unit": "lines/s", "cores": cores, "kind": "port",
+            "single_thread": {"value": lines_one / secs1, "unit": "lines/s", "cores": 1,
+                              "sample": "first %d %s" % (lines_one, what)},
+            "sample": "first %d %s of the same recording, fp64 C oracle (restated "
+                      "SpectralService.computeMagnitudes), %d pthreads; single_thread = the same on one thread, "
+                      "as the reference's JavaFX thread" % (lines_all, what, cores)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # the clock needs ~10 launches to settle
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: cfg2 on one GPU, cfg3 (the sharded configuration) on several")
     ap.add_argument("--log2-samples", type=int, default=None, help="override samples per GPU (debug)")
+    ap.add_argument("--n-psd", type=int, default=None, help="cfg4: PSDs per GPU and step (default 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2-samples", type=int, default=28, help="CPU baseline sample: first 2^k samples")
+    ap.add_argument("--gather-steps", type=int, default=3, help="N > 1: steps of the compute+gather timing")
+    ap.add_argument("--gather-chunks", type=int, default=8)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="spec_set_option knob for experiments, e.g. --opt large_team=0 (repeatable)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,6 +108,8 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
+    if args.workload is None:
+        args.workload = "cfg2" if world == 1 else "cfg3"
     # SPEC_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a ONE-GPU box -- every rank on device 0,
     # gloo instead of RCCL (which refuses two ranks on one device).  Never used by the driver.
     rehearse = os.environ.get("SPEC_BENCH_REHEARSE") == "1"
@@ -88,34 +123,56 @@ def main() -> None:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    red_dev = "cpu" if rehearse else None  # device of the two scalar reductions
+    red_dev = "cpu" if rehearse else None  # device of the scalar reductions
 
     import spectral_analyzer_amd as sa
     from spectral_analyzer_amd import _lib as L
+    from spectral_analyzer_amd import dist as sd
 
-    datatype, nfft, hop, log2s, window = WORKLOADS[args.workload]
-    if args.log2_samples is not None:
-        log2s = args.log2_samples
+    w = dict(WORKLOADS[args.workload])
+    datatype, nfft, hop, window = w["datatype"], w["nfft"], w["hop"], w["window"]
     bps = sa.bytes_per_sample(datatype)
-    per_gpu = 1 << log2s
-    total_samples = per_gpu * world
-    total_lines = (total_samples - nfft) // hop + 1
-    l0, l1 = rank * total_lines // world, (rank + 1) * total_lines // world
-    n_lines = l1 - l0
-    first_sample = l0 * hop
-    n_samples = (n_lines - 1) * hop + nfft  # includes the nfft-hop halo shared with the next rank
+    welch = w["kind"] == "welch"
 
     # a real (non-null) stream shared by torch and the library, so that the HIP
     # events below bracket exactly the kernels the C ABI launches
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     svc = sa.SpectralService(local_rank, stream=stream.cuda_stream)
-    iq = svc.synth_iq(datatype, SEED, first_sample, n_samples)
-    out = torch.empty((n_lines, nfft), dtype=torch.float32, device=iq.device)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        svc.set_option(key, int(val))
 
-    def step():
-        svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window,
-                              out_fmt=L.OUT_DB20_F32, out=out)
+    if welch:
+        n_seg = w["n_seg"]
+        n_psd = args.n_psd or w["n_psd"]
+        per_psd = (n_seg - 1) * hop + nfft                      # samples of one PSD (one annotation)
+        n_samples = per_psd * n_psd
+        first_sample = rank * n_samples
+        iq = svc.synth_iq(datatype, SEED, first_sample, n_samples)
+        out = torch.empty((n_psd, nfft), dtype=torch.float32, device=iq.device)
+        n_lines = n_psd * n_seg                                   # segments ("lines") per GPU and step
+        total_lines = n_lines * world
+        log2s = None
+        fs = 1.0e6
+
+        def step():
+            svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=window, n_psd=n_psd,
+                          psd_stride_bytes=per_psd * bps, out=out)
+    else:
+        log2s = args.log2_samples if args.log2_samples is not None else w["log2s"]
+        per_gpu = 1 << log2s
+        total_lines = (per_gpu * world - nfft) // hop + 1
+        l0, l1 = sd.shard_lines(total_lines, world, rank)
+        n_lines = l1 - l0
+        first_sample, n_samples = sd.shard_span(l0, l1, nfft, hop)  # includes the nfft - hop halo
+        iq = svc.synth_iq(datatype, SEED, first_sample, n_samples)
+        out_fmt = L.OUT_DB20_F64 if w["out"] == "f64" else L.OUT_DB20_F32
+        out = torch.empty((n_lines, nfft), dtype=torch.float64 if w["out"] == "f64" else torch.float32,
+                          device=iq.device)
+
+        def step():
+            svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=out_fmt, out=out)
 
     def fence():
         torch.cuda.synchronize()
@@ -137,44 +194,88 @@ def main() -> None:
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev or iq.device)
+        t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=red_dev or iq.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kern_ms], dtype=torch.float64, device=red_dev or iq.device)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kern_ms = float(k.item())
+        elapsed, kern_ms = float(t[0].item()), float(t[1].item())
 
-    # spot check outside the timed region: a few of this rank's lines against the oracle
+    # ---- N > 1: the same step with the tiles gathered on rank 0, chunk sends overlapped with compute ----
+    gather = None
+    if dist is not None and not welch:
+        try:
+            chunks = max(1, args.gather_chunks)
+            comm = torch.cuda.Stream()
+            full = torch.empty((total_lines, nfft), dtype=out.dtype, device=out.device) if rank == 0 else None
+
+            def compute_rows(a, b, view):
+                svc.compute_waterfall(iq, (a - l0) * hop * bps, nfft, datatype, b - a, hop=hop, window=window,
+                                      out_fmt=out_fmt, out=view)
+
+            def gstep():
+                sd.sharded_waterfall_overlapped(compute_rows, total_lines, nfft, n_chunks=chunks, dst=0,
+                                                out=full if rank == 0 else out, comm_stream=comm)
+
+            gstep()
+            fence()
+            g0 = time.perf_counter()
+            for _ in range(max(1, args.gather_steps)):
+                gstep()
+            fence()
+            gsec = (time.perf_counter() - g0) / max(1, args.gather_steps)
+            t = torch.tensor([gsec], dtype=torch.float64, device=red_dev or iq.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gsec = float(t.item())
+            ok = None
+            if rank == 0:  # the root's own rows of the gathered tile are the lines the plain step produced
+                ok = bool(torch.equal(full[l0:l1], out))
+            peer_bytes = (total_lines - n_lines) * nfft * out.element_size()
+            gather = {"value": total_lines / gsec, "unit": "lines/s", "ms_per_step": gsec * 1e3, "chunks": chunks,
+                      "steps": max(1, args.gather_steps), "GBps_into_root": peer_bytes / gsec / 1e9,
+                      "root_rows_equal_plain_step": ok,
+                      "what": "compute + gather of every rank's tile on rank 0: %d chunk sends per rank on a second "
+                              "stream behind the chunk's kernels (dist.sharded_waterfall_overlapped)" % chunks}
+            del full
+        except Exception as e:  # the gather timing must never take the headline down with it
+            gather = {"error": repr(e)}
+
+    # ---- outside the timed region: spot check against the oracle, CPU baseline ----
     checked = None
     cpu_baseline = None
     if rank == 0:
         from oracle import spec_oracle as so
         so.build()
-        pick = sorted(set(int(x) for x in np.linspace(0, n_lines - 1, 6)))
-        worst = 0.0
-        for ln in pick:
-            raw = iq[ln * hop * bps:(ln * hop + nfft) * bps].cpu().numpy()
-            ref = so.waterfall(raw, 0, datatype, nfft, hop, 1, window)[0]
-            got = out[ln].cpu().numpy().astype(np.float64)
-            m_ref, m_got = 10 ** (ref / 20), 10 ** (got / 20)
-            worst = max(worst, float(np.abs(m_got - m_ref).max() / (m_ref.max() * np.log2(nfft))))
-        checked = {"lines": len(pick), "max_lin_err_over_M_log2N": worst, "tol": 4e-6, "ok": bool(worst <= 4e-6)}
+        if welch:
+            pick = sorted(set(int(x) for x in np.linspace(0, n_psd - 1, 3)))
+            worst = 0.0
+            for p in pick:
+                raw = iq[p * per_psd * bps:(p + 1) * per_psd * bps].cpu().numpy()
+                _, ref = so.welch_psd(raw, 0, datatype, nfft, hop, n_seg, window, so.PSD_DENSITY, fs)
+                worst = max(worst, float(np.abs(out[p].cpu().numpy() - ref).max() / ref.max()))
+            checked = {"psds": len(pick), "max_err_over_peak": worst, "tol": 5e-6, "ok": bool(worst <= 5e-6)}
+        else:
+            pick = sorted(set(int(x) for x in np.linspace(0, n_lines - 1, 6)))
+            worst = 0.0
+            for ln in pick:
+                raw = iq[ln * hop * bps:(ln * hop + nfft) * bps].cpu().numpy()
+                ref = so.waterfall(raw, 0, datatype, nfft, hop, 1, window)[0]
+                got = out[ln].cpu().numpy().astype(np.float64)
+                m_ref, m_got = 10 ** (ref / 20), 10 ** (got / 20)
+                worst = max(worst, float(np.abs(m_got - m_ref).max() / (m_ref.max() * np.log2(nfft))))
+            tol = 8e-15 if w["out"] == "f64" else 4e-6
+            checked = {"lines": len(pick), "max_lin_err_over_M_log2N": worst, "tol": tol, "ok": bool(worst <= tol)}
 
         if world == 1 and not args.no_cpu_baseline:
-            cs = min(1 << args.cpu_log2_samples, n_samples)
-            host = iq[:cs * bps].cpu().numpy()
-            cl = (cs - nfft) // hop + 1
-            cores = usable_cores()
-            secs, _ = so.time_waterfall(host, datatype, nfft, hop, cl, window, cores)
-            cpu_baseline = {"value": cl / secs, "unit": "lines/s", "cores": cores, "kind": "port",
-                            "sample": "first 2^%d samples of the same recording (%d lines), fp64 C oracle "
-                                      "(restated SpectralService.computeMagnitudes), %d pthreads"
-                                      % (int(np.log2(cs)), cl, cores)}
+            # bounded samples: roughly 1e9 butterfly-points for the all-core run, 1.5e8 for the single thread
+            per_line = nfft * np.log2(nfft)
+            la = int(max(8, min(n_lines, 1.6e9 / per_line)))
+            l1t = int(max(4, min(n_lines, 2.0e8 / per_line)))
+            host = iq[:((la - 1) * hop + nfft) * bps].cpu().numpy()
+            cpu_baseline = cpu_baseline_for(so, host, datatype, nfft, hop, window, la, l1t,
+                                            "segments (Hann, hop %d)" % hop if welch else "lines")
 
     # calibration outside the timed region ("calibrate with a device memcpy"): what a
     # plain device-to-device copy of the output tile moves per second on THIS box, read + write
     copy_gbps = None
-    if rank == 0 and n_lines * nfft * 4 >= (1 << 28):
+    if rank == 0 and out.numel() * out.element_size() >= (1 << 28):
         dst = torch.empty_like(out)
         for _ in range(3):
             dst.copy_(out)
@@ -184,67 +285,63 @@ def main() -> None:
             dst.copy_(out)
             b.record(stream)
         torch.cuda.synchronize()
-        copy_gbps = 2.0 * out.numel() * 4 / (float(np.median([a.elapsed_time(b) for a, b in cev])) * 1e-3) / 1e9
+        copy_gbps = 2.0 * out.numel() * out.element_size() / (float(np.median([a.elapsed_time(b) for a, b in cev])) * 1e-3) / 1e9
         del dst
 
     if rank == 0:
-        lines_all = total_lines * args.steps
-        value = lines_all / elapsed
-        b_line = hop * bps + nfft * 4  # every sample read once, every bin written once
-        achieved = n_lines * b_line / (kern_ms * 1e-3) / 1e9
+        value = total_lines * args.steps / elapsed
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.log2_samples is None and args.n_psd is None:
             try:
-                traffic = json.load(open(tpath)).get(args.workload if log2s == WORKLOADS[args.workload][3] else "")
+                traffic = json.load(open(tpath)).get(args.workload)
             except Exception:
                 traffic = None
+        if welch:
+            # B_psd = S bps_in + 4 N; 5 N log2 N flops per segment.  35 flop per byte: the vector
+            # ALUs bound this kernel, not HBM -- the roofline is the fp32 vector peak, the HBM figure rides along
+            b_psd = per_psd * bps + nfft * 4
+            flops = 5.0 * nfft * np.log2(nfft) * n_lines
+            tfl = flops / (kern_ms * 1e-3) / 1e12
+            hbm = n_psd * b_psd / (kern_ms * 1e-3) / 1e9
+            roof = {"bound": "valu", "achieved": tfl, "peak": FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tfl / FP32_VECTOR_TFLOPS, "traffic": traffic, "kernel_ms": kern_ms,
+                    "flops_per_segment": 5.0 * nfft * np.log2(nfft), "segments_per_launch": n_lines,
+                    "hbm_achieved_GBps": hbm, "hbm_frac": hbm / HBM_PEAK_GBPS, "bytes_per_psd": b_psd,
+                    "psd_per_s": n_psd * world * args.steps / elapsed}
+            metric = "Welch PSD segments/sec (%d-pt FFT, Hann, %d %% overlap, %d-segment average)" % (
+                nfft, round(100 * (1 - hop / nfft)), n_seg)
+            workload = "%s: Welch %d-pt, hop %d, %s, %d segments per PSD, %d PSDs per GPU and step, fp32 PSD out" % (
+                args.workload, nfft, hop, datatype, n_seg, n_psd)
+        else:
+            osz = out.element_size()
+            b_line = hop * bps + nfft * osz  # every sample read once, every bin written once
+            achieved = n_lines * b_line / (kern_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                    "kernel_ms": kern_ms, "bytes_per_line": b_line, "lines_per_launch": n_lines,
+                    # extras: reads only (the north star is phrased on reads) and the box's own copy rate
+                    "read_frac": n_lines * hop * bps / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "copy_GBps": copy_gbps,
+                    "frac_of_copy": (achieved / copy_gbps) if copy_gbps else None}
+            metric = ("spectrogram lines/sec (4096-pt FFT, 50% overlap)" if nfft == 4096 else
+                      "spectrogram lines/sec (%d-pt FFT, %d %% overlap)" % (nfft, round(100 * (1 - hop / nfft))))
+            workload = "%s: %d-pt FFT, hop %d, %s, 2^%d samples per GPU, %d lines total, %s out" % (
+                args.workload, nfft, hop, datatype, log2s, total_lines, "DB20_F64" if w["out"] == "f64" else "DB20_F32")
         res = {
-            "metric": "spectrogram lines/sec (4096-pt FFT, 50% overlap)" if nfft == 4096 else
-                      "spectrogram lines/sec (%d-pt FFT)" % nfft,
+            "metric": metric,
             "value": value, "unit": "lines/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d-pt FFT, hop %d, %s, 2^%d samples per GPU, %d lines total, DB20_F32 out"
-                                   % (args.workload, nfft, hop, datatype, log2s, total_lines),
-                       "window": "rect" if window == 0 else "hann", "sharding": "time-slice x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "bytes_per_line": b_line, "lines_per_launch": n_lines,
-                         # extras: reads only (the north star is phrased on reads) and the box's own copy rate
-                         "read_frac": n_lines * hop * bps / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "copy_GBps": copy_gbps,
-                         "frac_of_copy": (achieved / copy_gbps) if copy_gbps else None},
+            "vs_baseline": None, "dtype": "f64" if (not welch and w["out"] == "f64") else "f32", "data": "synthetic",
+            "config": {"workload": workload, "window": "rect" if window == 0 else "hann",
+                       "sharding": "time-slice x%d" % world, **({"options": args.opt} if args.opt else {})},
+            "roofline": roof,
             "cpu_baseline": cpu_baseline,
             "parity_spot_check": checked,
         }
+        if gather is not None:
+            res["gather"] = gather
         print(json.dumps(res), flush=True)
-    # outside the timed region: the tile gather of SURVEY 8(e) on a bounded slice (the first
-    # <= 4096 lines of every rank) through direct peer -> root sends; reported on stderr AFTER the bench line is out, never part of `value`
-    if dist is not None:
-        try:
-            gl = min(n_lines, 4096)
-            tile = out[:gl]
-            torch.cuda.synchronize()
-            dist.barrier()
-            g0 = time.perf_counter()
-            if rank == 0:
-                full = torch.empty((gl * world, nfft), dtype=out.dtype, device=out.device)
-                full[:gl].copy_(tile)
-                ops = [dist.P2POp(dist.irecv, full[r * gl:(r + 1) * gl], r) for r in range(1, world)]
-            else:
-                ops = [dist.P2POp(dist.isend, tile, 0)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            torch.cuda.synchronize()
-            dist.barrier()
-            gms = (time.perf_counter() - g0) * 1e3
-            if rank == 0:
-                print(json.dumps({"gather": {"lines_per_rank": gl, "ms": gms,
-                                             "GBps_into_root": (world - 1) * gl * nfft * 4 / gms / 1e6}}),
-                      file=sys.stderr, flush=True)
-        except Exception as e:  # the demonstration must never break the run
-            print("gather demonstration failed: %r" % (e,), file=sys.stderr, flush=True)
 
     if dist is not None:
         dist.destroy_process_group()

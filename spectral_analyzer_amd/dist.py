@@ -41,35 +41,112 @@ def total_lines(n_samples: int, nfft: int, hop: int) -> int:
 
 
 def gather_tiles(tile: torch.Tensor, total: int, nfft: int, dst: int = 0,
-                 group: Optional[dist.ProcessGroup] = None) -> Optional[torch.Tensor]:
+                 group: Optional[dist.ProcessGroup] = None, n_chunks: int = 1,
+                 out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Gather the per-rank tiles ``[lines_r, nfft]`` into ``[total, nfft]`` on ``dst``.
 
-    Tiles may have different heights (L not divisible by R): the root posts one
-    receive per peer straight into the right rows of the result, every peer
-    posts one send -- a grouped send/recv, no padding, no staging copy.
+    Tiles may have different heights (L not divisible by R): the root posts
+    receives straight into the right rows of the result (``out`` when given, so a
+    caller that gathers repeatedly keeps ONE full tile), every peer posts sends -- grouped
+    send/recv, no padding, no staging copy.  ``n_chunks`` > 1 moves every tile in that many
+    pieces (one grouped exchange per piece) instead of one message of up to 8 GiB per peer.
     """
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     l0, l1 = shard_lines(total, world, rank)
     if tile.shape != (l1 - l0, nfft):
         raise ValueError("rank %d tile is %s, expected (%d, %d)" % (rank, tuple(tile.shape), l1 - l0, nfft))
     tile = tile.contiguous()
+    n_chunks = max(1, int(n_chunks))
     if rank == dst:
-        out = torch.empty((total, nfft), dtype=tile.dtype, device=tile.device)
+        if out is None:
+            out = torch.empty((total, nfft), dtype=tile.dtype, device=tile.device)
+        elif out.shape != (total, nfft) or out.dtype != tile.dtype:
+            raise ValueError("out is %s %s, expected (%d, %d) %s" % (tuple(out.shape), out.dtype, total, nfft, tile.dtype))
         out[l0:l1].copy_(tile)
-        ops = []
-        for r in range(world):
-            if r == dst:
-                continue
-            a, b = shard_lines(total, world, r)
-            if b > a:
-                ops.append(dist.P2POp(dist.irecv, out[a:b], r, group))
-        for w in (dist.batch_isend_irecv(ops) if ops else []):
+        peers = {r: chunk_bounds(*shard_lines(total, world, r), n_chunks) for r in range(world) if r != dst}
+        works = []
+        for j in range(n_chunks):
+            ops = [dist.P2POp(dist.irecv, out[ch[j][0]:ch[j][1]], r, group) for r, ch in peers.items() if ch[j][1] > ch[j][0]]
+            if ops:
+                works.extend(dist.batch_isend_irecv(ops))
+        for w in works:
             w.wait()
         return out
-    if l1 > l0:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, tile, dst, group)]):
-            w.wait()
+    works = []
+    for a, b in chunk_bounds(l0, l1, n_chunks):
+        if b > a:
+            works.extend(dist.batch_isend_irecv([dist.P2POp(dist.isend, tile[a - l0:b - l0], dst, group)]))
+    for w in works:
+        w.wait()
     return None
+
+
+def chunk_bounds(l0: int, l1: int, n_chunks: int):
+    """[l0, l1) cut into n_chunks consecutive pieces (some may be empty when the range is short)."""
+    n = l1 - l0
+    return [(l0 + n * j // n_chunks, l0 + n * (j + 1) // n_chunks) for j in range(n_chunks)]
+
+
+def sharded_waterfall_overlapped(compute_rows: Callable[[int, int, torch.Tensor], None], total: int, nfft: int,
+                                 n_chunks: int = 8, dst: int = 0, dtype: torch.dtype = torch.float32,
+                                 device=None, out: Optional[torch.Tensor] = None, comm_stream=None,
+                                 group: Optional[dist.ProcessGroup] = None) -> Optional[torch.Tensor]:
+    """Compute this rank's lines chunk by chunk and send every finished chunk to ``dst`` while the
+    next one is being computed (gather overlapped with compute on a second stream).
+
+    ``compute_rows(a, b, view)`` writes lines [a, b) into ``view`` (a ``[b - a, nfft]`` slice).  On the
+    root ``view`` is a slice of the full ``[total, nfft]`` tile itself -- the root computes its own lines
+    in place and posts one grouped receive per chunk index straight into the peers' rows, so it never
+    holds a second copy of anything; the peers send from their own ``[lines_r, nfft]`` tile.  Every rank
+    cuts its range into the same number of chunks, so chunk j of every peer is matched by the root's
+    j-th grouped receive.  On CUDA tensors the transfers are issued under ``comm_stream`` behind an
+    event recorded after the chunk's kernels: RCCL then orders them after that chunk only, and the
+    compute stream runs ahead.  Returns the full tile on ``dst``, None elsewhere.
+    """
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    l0, l1 = shard_lines(total, world, rank)
+    if rank == dst:
+        full = out if out is not None else torch.empty((total, nfft), dtype=dtype, device=device)
+        if full.shape != (total, nfft):
+            raise ValueError("root tile is %s, expected (%d, %d)" % (tuple(full.shape), total, nfft))
+        mine = full[l0:l1]
+    else:
+        full = None
+        mine = out if out is not None else torch.empty((l1 - l0, nfft), dtype=dtype, device=device)
+        if mine.shape != (l1 - l0, nfft):
+            raise ValueError("rank %d tile is %s, expected (%d, %d)" % (rank, tuple(mine.shape), l1 - l0, nfft))
+    on_gpu = mine.is_cuda
+    if on_gpu and comm_stream is None:
+        comm_stream = torch.cuda.Stream(device=mine.device)
+    my_chunks = chunk_bounds(l0, l1, n_chunks)
+    peer_chunks = {r: chunk_bounds(*shard_lines(total, world, r), n_chunks) for r in range(world) if r != dst}
+    works = []
+    for j, (a, b) in enumerate(my_chunks):
+        if b > a:
+            compute_rows(a, b, mine[a - l0:b - l0])
+        ops = []
+        if rank == dst:
+            for r, ch in peer_chunks.items():
+                ra, rb = ch[j]
+                if rb > ra:
+                    ops.append(dist.P2POp(dist.irecv, full[ra:rb], r, group))
+        elif b > a:
+            ops.append(dist.P2POp(dist.isend, mine[a - l0:b - l0], dst, group))
+        if not ops:
+            continue
+        if on_gpu:
+            ev = torch.cuda.Event()
+            ev.record()                                   # after this chunk's kernels on the compute stream
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                works.extend(dist.batch_isend_irecv(ops))
+        else:
+            works.extend(dist.batch_isend_irecv(ops))
+    for w in works:
+        w.wait()
+    if on_gpu:
+        torch.cuda.current_stream().wait_stream(comm_stream)
+    return full
 
 
 def sharded_waterfall(compute_tile: Callable[[int, int], torch.Tensor], total: int, nfft: int,

@@ -224,7 +224,7 @@ class SpectralService:
     def welch_psd(self, buffer, start_byte: int, datatype: str, fs: float, nfft: int = 8192,
                   hop: Optional[int] = None, n_seg: Optional[int] = None, window: int = L.WIN_HANN,
                   scaling: int = L.PSD_DENSITY, db: bool = False, n_psd: int = 1,
-                  psd_stride_bytes: int = 0) -> Tuple[np.ndarray, object]:
+                  psd_stride_bytes: int = 0, out=None) -> Tuple[np.ndarray, object]:
         """Welch PSD; returns ``(freq[nfft], psd[n_psd, nfft])`` like the two
         rows the reference plots (ADC:324-328).  ``hop`` defaults to nfft/2 and
         ``n_seg`` to every whole segment available after ``start_byte``."""
@@ -244,7 +244,13 @@ class SpectralService:
             n_seg = int(self._lib.spec_count_lines(n_bytes, int(start_byte), dt, int(nfft), hop))
         freq = np.empty(int(nfft), dtype=np.float64)
         if on_dev:
-            psd = torch.empty((int(n_psd), int(nfft)), dtype=torch.float32, device=buffer.device)
+            if out is None:
+                psd = torch.empty((int(n_psd), int(nfft)), dtype=torch.float32, device=buffer.device)
+            else:
+                psd = out
+                if (not _is_torch(psd) or not psd.is_cuda or psd.dtype != torch.float32 or not psd.is_contiguous()
+                        or psd.numel() < n_psd * nfft):
+                    raise ValueError("out tensor has the wrong dtype/size")
             out_ptr = psd.data_ptr()
         else:
             psd = np.empty((int(n_psd), int(nfft)), dtype=np.float32)

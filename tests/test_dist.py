@@ -59,6 +59,20 @@ def _worker(rank, world, port, total, q):
             iq = so.synth_iq(dt, seed, first, n)
             return torch.from_numpy(so.waterfall(iq, 0, dt, nfft, hop, s1 - s0, so.WIN_HANN, power=True).sum(axis=0))
 
+        # the chunked forms: tile gathered in pieces into a caller-owned root tile, and the
+        # compute-chunk / send-chunk pipeline (on CPU tensors the "second stream" is absent)
+        own = torch.empty((total, nfft), dtype=torch.float32) if rank == 0 else None
+        chunked = sd.gather_tiles(local, total, nfft, dst=0, n_chunks=3, out=own)
+
+        def compute_rows(a, b, view):
+            view.copy_(compute_tile(a, b))
+
+        piped = sd.sharded_waterfall_overlapped(compute_rows, total, nfft, n_chunks=4, dst=0, device="cpu")
+        if rank == 0:
+            assert chunked is own and torch.equal(chunked, full) and torch.equal(piped, full)
+        else:
+            assert chunked is None and piped is None
+
         w = so.np_window(nfft, so.WIN_HANN)
         psd = sd.sharded_welch(partial_power, total, 1.0 / (1.0 * (w ** 2).sum()))
         if rank == 0:

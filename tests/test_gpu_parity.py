@@ -4,11 +4,21 @@ same seeded inputs.  Tolerances are the ones stated in SURVEY.md 8(c):
 fp32 pipeline (reference is fp64):  with M = max_k |X[k]| of the line,
     * every bin:                 | |X|_gpu - |X|_ref |  <=  4e-6 * M * log2(N)
     * bins with |X| >= 1e-3 * M: | dB_gpu - dB_ref |    <=  2e-3 dB
-    * bins with |X| >= 1e-4 * M: | dB_gpu - dB_ref |    <=  2e-2 dB
+    * bins with |X| >= 1e-4 * M: | dB_gpu - dB_ref |    <=  4e-3 dB
   (the fp32 FFT adds a noise floor of about 3 eps sqrt(log2 N) ||x||_2 rms to every
   bin -- measured with tools/errstats.py -- so the dB error of a bin grows as the bin
-  gets weaker; SURVEY 8(c) guessed 2e-3 dB down to 1e-4 M before anything was measured)
-fp64 pipeline (DB20_F64 / cf64): | dB_gpu - dB_ref | <= 1e-9 dB on bins with |X| >= 1e-9 * M
+  gets weaker: <= 4e-4 dB measured at 1e-3 M, 1-2e-3 dB at 1e-4 M.  SURVEY 8(c) / BASELINE.md 3
+  state 2e-3 dB down to 1e-4 M, written before anything was measured; the two-tier statement
+  above is the one the build holds, and test_observed_fp32_error_per_tier prints the maxima)
+fp64 pipeline (DB20_F64 / cf64), the same two forms with fp64's epsilon:
+    * every bin with |X| >= 1e-9 * M:  | |X|_gpu - |X|_ref |  <=  8e-15 * M * log2(N)
+      (= the fp32 bound scaled by eps64 / eps32)
+    * bins with |X| >= 1e-5 * M:       | dB_gpu - dB_ref |    <=  1e-9 dB
+  SURVEY 8(c) states the 1e-9 dB down to 1e-9 M; no fp64 transform can deliver that: both the oracle
+  and the GPU carry an absolute error of a few 1e-16 M per bin, which on a bin of 1e-6 M is already
+  1e-10 relative = 1e-9 dB (first seen on 1 of 2.4 million bins of a 16384-point case whose noise
+  floor happened to have a deep null).  Hence the dB form holds from 1e-5 M up and the linear form
+  covers every bin.
 """
 import numpy as np
 import pytest
@@ -29,14 +39,19 @@ def check_fp32(db_gpu, db_ref, nfft):
     assert lin_err.max() <= 4e-6, "linear error %.3g > 4e-6 M log2 N" % lin_err.max()
     db_abs = np.abs(db_gpu.astype(np.float64) - db_ref)
     assert db_abs[mag_r >= 1e-3 * M].max() <= 2e-3, "dB error %.3g on bins >= 1e-3 M" % db_abs[mag_r >= 1e-3 * M].max()
-    assert db_abs[mag_r >= 1e-4 * M].max() <= 2e-2, "dB error %.3g on bins >= 1e-4 M" % db_abs[mag_r >= 1e-4 * M].max()
+    assert db_abs[mag_r >= 1e-4 * M].max() <= 4e-3, "dB error %.3g on bins >= 1e-4 M" % db_abs[mag_r >= 1e-4 * M].max()
+    return lin_err.max(), db_abs[mag_r >= 1e-3 * M].max(), db_abs[mag_r >= 1e-4 * M].max()
 
 
 def check_fp64(db_gpu, db_ref):
+    nfft = db_ref.shape[-1]
     mag_r = 10.0 ** (db_ref / 20.0)
+    mag_g = 10.0 ** (db_gpu.astype(np.float64) / 20.0)
     M = mag_r.max(axis=1, keepdims=True)
-    strong = mag_r >= 1e-9 * M
-    err = np.abs(db_gpu - db_ref)[strong]
+    seen = mag_r >= 1e-9 * M            # below that the +1e-10 of SS:81 takes over
+    lin = (np.abs(mag_g - mag_r) / (M * np.log2(max(nfft, 2))))[seen]
+    assert lin.max() <= 8e-15, "fp64 linear error %.3g > 8e-15 M log2 N" % lin.max()
+    err = np.abs(db_gpu - db_ref)[mag_r >= 1e-5 * M]
     assert err.max() <= 1e-9, "fp64 dB error %.3g" % err.max()
 
 
@@ -154,3 +169,21 @@ def test_extreme_magnitudes_and_nan(svc, oracle, nfft):
     assert list(bad) == [False, True, True, False, False, False]
     assert np.isnan(got[bad]).all() and np.isfinite(got[~bad]).all()
     check_fp32(got[~bad], ref[~bad], nfft)
+
+
+def test_observed_fp32_error_per_tier(svc, oracle, capsys):
+    """Prints the observed maxima of the three fp32 tolerance tiers (run with -s, or read them in the
+    GPU test log) for the headline sizes; the asserts are the stated tolerances themselves."""
+    rows = []
+    for datatype in ("cf32_le", "ci16_le", "cu8"):
+        for nfft in (1024, 4096, 16384):
+            hop, n_lines = nfft // 2, 64
+            iq = oracle.synth_iq(datatype, seed=1234 + nfft, first_sample=0, n_samples=(n_lines - 1) * hop + nfft)
+            ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines)
+            got = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop)
+            rows.append((datatype, nfft) + check_fp32(got, ref, nfft))
+    with capsys.disabled():
+        print("\nfp32 pipeline vs fp64 oracle: max linear error / (M log2 N) [tol 4e-6], "
+              "max |dB| on bins >= 1e-3 M [tol 2e-3], on bins >= 1e-4 M [tol 4e-3]")
+        for r in rows:
+            print("  %-8s nfft %5d   %.3g   %.3g dB   %.3g dB" % r)
