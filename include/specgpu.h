@@ -120,7 +120,8 @@ void *spec_stream(const spec_ctx *ctx);
  *                     with the two-launch path behind it as a guarded fall-back; 0 = two-launch path only; 2 = the
  *                     persistent launch for any number of lines and no fall-back (the call then waits for the
  *                     kernel and returns SPEC_EDEVICE if one of its bounded waits timed out)
- *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 2)
+ *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 3)
+ *   "large_wg" = 256 | 512  threads per workgroup of the persistent launch (default 512: 16-bin = 128-byte output runs)
  *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
  *   "render_fused" = 0 | 1   spec_waterfall_render stores only the bins the image samples (default 1; 0 = full
  *                     dB tile, then the colour kernel: the two forms give identical pixels)
@@ -176,6 +177,34 @@ spec_status spec_waterfall(spec_ctx *ctx, const void *iq, int iq_on_device, uint
                            uint64_t start_byte, spec_dtype dt, uint32_t nfft, uint32_t hop,
                            uint64_t n_lines, spec_window window, spec_out_fmt out_fmt,
                            double eof_fill, void *out, int out_on_device);
+
+/* ---- recordings on disk (SURVEY 8f "next" #3) ------------------------------ */
+
+/* Replaces the mapping step of SigMfHelper.load (sigmf/SigMfHelper.java:69-94): the reference maps at
+ * most Integer.MAX_VALUE bytes of the data file (SMH:78-84) and addresses them with int offsets
+ * (MainController.java:985, SS:33), so only the first 2 GiB of a recording can be shown.  A
+ * spec_recording is the data file itself -- `data_path` as SigMfHelper resolves it (core:dataset or
+ * the .sigmf-data sibling, SMH:49-57), `header_bytes` = captures[0] core:header_bytes (SMH:60-67) --
+ * with 64-bit offsets and no size limit.  The library reads the slices it needs with pread into a
+ * pinned two-slot ring that feeds the same two-deep device pipeline as spec_waterfall. */
+typedef struct spec_recording spec_recording;
+spec_status spec_open_recording(spec_ctx *ctx, const char *data_path, uint64_t header_bytes,
+                                spec_recording **out);
+/* payload bytes after the header: max(0, file size - header_bytes) (SMH:74-76), the `capacity` of
+ * the buffer the reference would have mapped, without the cap */
+uint64_t spec_recording_bytes(const spec_recording *rec);
+void spec_close_recording(spec_recording *rec);
+
+/* spec_waterfall over a recording on disk; start_byte counts from the end of the header. */
+spec_status spec_waterfall_recording(spec_ctx *ctx, const spec_recording *rec, uint64_t start_byte,
+                                     spec_dtype dt, uint32_t nfft, uint32_t hop, uint64_t n_lines,
+                                     spec_window window, spec_out_fmt out_fmt, double eof_fill, void *out,
+                                     int out_on_device);
+
+/* spec_compute_magnitudes (SS:33-85) with a 64-bit slice offset into a recording on disk. */
+spec_status spec_compute_magnitudes_recording(spec_ctx *ctx, const spec_recording *rec, uint64_t start_byte,
+                                              uint32_t nfft, const char *datatype, int big_endian,
+                                              double *out);
 
 /* ---- rendering (SURVEY 8f "next" #1) ------------------------------------- */
 

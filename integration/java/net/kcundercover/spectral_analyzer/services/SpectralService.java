@@ -132,6 +132,52 @@ public class SpectralService implements AutoCloseable {
         return out;
     }
 
+    /**
+     * A recording on disk, opened by the native library itself: path, header size and 64-bit offsets
+     * instead of the at most 2 GiB {@code MappedByteBuffer} of the reference's SigMfHelper.  Obtain the
+     * three values from the replacement {@code sigmf.SigMfHelper}:
+     * {@code openRecording(helper.getDataPath(), helper.getHeaderBytes())}.
+     */
+    public final class Recording implements AutoCloseable {
+        private long rec;
+
+        private Recording(long rec) {
+            this.rec = rec;
+        }
+
+        /** Payload bytes after the header (the mapped buffer's capacity, without the cap). */
+        public long length() {
+            return nativeRecordingBytes(rec);
+        }
+
+        /** {@code computeMagnitudes} with a 64-bit {@code startByte}. */
+        public double[] computeMagnitudes(long startByte, int nfft, String datatype, boolean bigEndian) {
+            double[] line = new double[Math.max(nfft, 0)];
+            nativeComputeMagnitudesRecording(handle, rec, startByte, nfft, datatype, bigEndian, line);
+            return line;
+        }
+
+        /** The whole slice loop of a redraw, read straight from the file; EOF lines are -150.0. */
+        public float[] computeWaterfall(long startByte, int nfft, int hop, int nLines, String datatype, int window) {
+            float[] tile = new float[Math.multiplyExact(nLines, nfft)];
+            nativeWaterfallRecording(handle, rec, startByte, nativeDtype(datatype), nfft, hop, nLines, window, -150.0, tile);
+            return tile;
+        }
+
+        @Override
+        public void close() {
+            if (rec != 0) {
+                nativeCloseRecording(rec);
+                rec = 0;
+            }
+        }
+    }
+
+    /** Opens the data file of a recording; {@code headerBytes} = {@code core:header_bytes} of the first capture. */
+    public Recording openRecording(java.nio.file.Path dataFile, long headerBytes) {
+        return new Recording(nativeOpenRecording(handle, dataFile.toString(), headerBytes));
+    }
+
     @Override
     public void close() {
         nativeDestroy(handle);
@@ -156,4 +202,13 @@ public class SpectralService implements AutoCloseable {
     private static native void nativeTrace(long handle, int which, double[] re, double[] im, double alpha,
                                            double sampleRate, double centerFreq, double[] out);
     private static native int nativeDtype(String datatype);
+    private static native long nativeOpenRecording(long handle, String path, long headerBytes);
+    private static native long nativeRecordingBytes(long recording);
+    private static native void nativeCloseRecording(long recording);
+    private static native void nativeWaterfallRecording(long handle, long recording, long startByte, int dtype,
+                                                        int nfft, int hop, long nLines, int window, double eofFill,
+                                                        float[] out);
+    private static native void nativeComputeMagnitudesRecording(long handle, long recording, long startByte,
+                                                                int nfft, String datatype, boolean bigEndian,
+                                                                double[] out);
 }

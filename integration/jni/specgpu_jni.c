@@ -163,6 +163,63 @@ JNIEXPORT void JNICALL JNI_FN(nativeWelchPlanar)(JNIEnv *env, jclass k, jlong h,
     if (st != SPEC_OK) throw_status(env, ctx, st);
 }
 
+/* ---- recordings on disk: SigMfHelper hands over path + header size instead of a <= 2 GiB mapping
+ * (SigMfHelper.java:69-94); offsets are jlong end to end ------------------------------------------- */
+JNIEXPORT jlong JNICALL JNI_FN(nativeOpenRecording)(JNIEnv *env, jclass k, jlong h, jstring path, jlong headerBytes) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    if (headerBytes < 0) { throw_shim(env, "openRecording: negative header size"); return 0; }
+    const char *p = (*env)->GetStringUTFChars(env, path, NULL);
+    spec_recording *rec = NULL;
+    spec_status st = spec_open_recording(ctx, p, (uint64_t)headerBytes, &rec);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (st != SPEC_OK) { throw_status(env, ctx, st); return 0; }
+    return (jlong)(intptr_t)rec;
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(nativeRecordingBytes)(JNIEnv *env, jclass k, jlong rec) {
+    (void)env; (void)k;
+    return (jlong)spec_recording_bytes((const spec_recording *)(intptr_t)rec);
+}
+
+JNIEXPORT void JNICALL JNI_FN(nativeCloseRecording)(JNIEnv *env, jclass k, jlong rec) {
+    (void)env; (void)k;
+    spec_close_recording((spec_recording *)(intptr_t)rec);
+}
+
+JNIEXPORT void JNICALL JNI_FN(nativeWaterfallRecording)(JNIEnv *env, jclass k, jlong h, jlong rec, jlong startByte,
+                                                         jint dtype, jint nfft, jint hop, jlong nLines, jint window,
+                                                         jdouble eofFill, jfloatArray out) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    if (startByte < 0 || nfft < 0 || nLines < 0 || (jlong)(*env)->GetArrayLength(env, out) < nLines * (jlong)nfft) {
+        throw_shim(env, "computeWaterfall(recording): negative argument or out shorter than nLines * nfft");
+        return;
+    }
+    jfloat *o = (*env)->GetFloatArrayElements(env, out, NULL);
+    spec_status st = spec_waterfall_recording(ctx, (const spec_recording *)(intptr_t)rec, (uint64_t)startByte,
+                                              (spec_dtype)dtype, (uint32_t)nfft, (uint32_t)hop, (uint64_t)nLines,
+                                              (spec_window)window, SPEC_OUT_DB20_F32, eofFill, o, 0);
+    (*env)->ReleaseFloatArrayElements(env, out, o, st == SPEC_OK ? 0 : JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
+JNIEXPORT void JNICALL JNI_FN(nativeComputeMagnitudesRecording)(JNIEnv *env, jclass k, jlong h, jlong rec,
+                                                                 jlong startByte, jint nfft, jstring datatype,
+                                                                 jboolean bigEndian, jdoubleArray out) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    if (nfft < 0 || (*env)->GetArrayLength(env, out) < nfft) { throw_shim(env, "computeMagnitudes(recording): out is shorter than nfft"); return; }
+    if (startByte < 0) { throw_msg(env, SPEC_ERANGE, "computeMagnitudes(recording): negative offset"); return; }
+    const char *dt = (*env)->GetStringUTFChars(env, datatype, NULL);
+    jdouble *o = (*env)->GetDoubleArrayElements(env, out, NULL);
+    spec_status st = spec_compute_magnitudes_recording(ctx, (const spec_recording *)(intptr_t)rec, (uint64_t)startByte,
+                                                       (uint32_t)nfft, dt, bigEndian ? 1 : 0, o);
+    (*env)->ReleaseDoubleArrayElements(env, out, o, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseStringUTFChars(env, datatype, dt);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
 JNIEXPORT jint JNICALL JNI_FN(nativeDtype)(JNIEnv *env, jclass k, jstring datatype) {
     (void)k;
     const char *dt = (*env)->GetStringUTFChars(env, datatype, NULL);

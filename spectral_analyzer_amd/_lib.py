@@ -12,6 +12,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspecgpu.so")
+# experiments only (tools/ablate.sh): SPEC_LIB_VARIANT=<name> loads lib/libspecgpu_<name>.so, a library built
+# with ablation macros whose results are wrong by construction; the product path never sets it
+if os.environ.get("SPEC_LIB_VARIANT"):
+    LIB_PATH = os.path.join(_HERE, "lib", "libspecgpu_%s.so" % os.environ["SPEC_LIB_VARIANT"])
 
 # spec_status
 SPEC_OK, SPEC_EINVAL, SPEC_ERANGE, SPEC_EDEVICE, SPEC_ENOMEM, SPEC_EUNSUPPORTED = range(6)
@@ -42,6 +46,11 @@ SIGNATURES = {
     "spec_count_lines": (_u64, [_u64, _u64, _i32, _u32, _u32]),
     "spec_compute_magnitudes": (_i32, [_vp, _vp, _u64, C.c_int64, _u32, _cp, _i32, _vp]),
     "spec_waterfall": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u64, _i32, _i32, _dbl, _vp, _i32]),
+    "spec_open_recording": (_i32, [_vp, _cp, _u64, C.POINTER(_vp)]),
+    "spec_recording_bytes": (_u64, [_vp]),
+    "spec_close_recording": (None, [_vp]),
+    "spec_waterfall_recording": (_i32, [_vp, _vp, _u64, _i32, _u32, _u32, _u64, _i32, _i32, _dbl, _vp, _i32]),
+    "spec_compute_magnitudes_recording": (_i32, [_vp, _vp, _u64, _u32, _cp, _i32, _vp]),
     "spec_welch_psd": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _u32, _i32, _u32, _u32, _u32, _i32, _i32,
                               _dbl, _i32, _vp, _vp, _i32]),
     "spec_render_spectrogram": (_i32, [_vp, _vp, _i32, _u32, _u32, _u32, _dbl, _dbl, _dbl, _i32, _vp, _i32]),

@@ -37,9 +37,8 @@ def _newest_dep() -> float:
     return max(os.path.getmtime(d) for d in deps)
 
 
-def _compile(src: str) -> str:
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
-    extra = os.environ.get("SPEC_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
+def _compile(src: str, objdir: str, extra) -> str:
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -47,20 +46,43 @@ def _compile(src: str) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_dep():
-        return LIB
+def _stamp(extra) -> str:
+    """What a library was built with: the product flags plus any experiment flags."""
+    return " ".join([*FLAGS, *extra])
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+    """Build the product library, or -- ``variant`` -- an EXPERIMENT library beside it
+    (lib/libspecgpu_<variant>.so, objects under build/<variant>/, compiled with ``extra_flags``, e.g. the
+    SPEC_ABL_* ablation macros whose results are wrong by construction).  An experiment never overwrites the
+    product: the product build takes no extra flags, and its freshness test also compares the flag stamp
+    stored beside the library, so a library built any other way is rebuilt."""
+    extra = list(extra_flags)
+    if variant:
+        lib = os.path.join(LIBDIR, "libspecgpu_%s.so" % variant)
+        objdir = os.path.join(OBJDIR, variant)
+    else:
+        if extra:
+            raise ValueError("the product library takes no extra flags; name a variant")
+        lib, objdir = LIB, OBJDIR
+    stamp_path = lib + ".flags"
+    fresh = (os.path.exists(lib) and os.path.getmtime(lib) >= _newest_dep() and os.path.exists(stamp_path)
+             and open(stamp_path).read() == _stamp(extra))
+    if fresh and not force:
+        return lib
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(_compile, SOURCES))
-    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB, *objs]
+        objs = list(ex.map(lambda src: _compile(src, objdir, extra), SOURCES))
+    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    with open(stamp_path, "w") as f:
+        f.write(_stamp(extra))
     if verbose:
-        print("built", LIB)
-    return LIB
+        print("built", lib)
+    return lib
 
 
 def build_jni(verbose: bool = False):
@@ -85,6 +107,12 @@ def build_jni(verbose: bool = False):
 
 
 if __name__ == "__main__":
+    # python -m spectral_analyzer_amd.build [--force] [--variant NAME -- -DSPEC_ABL_X ...]
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        flags = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
+        build(force=True, verbose=True, variant=sys.argv[i + 1], extra_flags=flags)
+        sys.exit(0)
     build(force="--force" in sys.argv, verbose=True)
     if "--jni" in sys.argv:
         build_jni(verbose=True)

@@ -3,6 +3,11 @@
 // table cache, host<->device staging, launch sequencing.  No CPU compute path.
 #include "../../include/specgpu.h"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -44,11 +49,15 @@ struct spec_ctx {
     void *scratch = nullptr;   size_t scratch_bytes = 0;   // large-N transposes, Welch slabs
     void *scratch2 = nullptr;  size_t scratch2_bytes = 0;  // fallback Welch: power lines + accumulator
     void *planar = nullptr;    size_t planar_bytes = 0;
+    // pinned host ring of the recording reader (spec_waterfall_recording): two slots the file is pread into,
+    // each copied to the device by an asynchronous (truly overlapped) transfer
+    void *pin_in = nullptr;    size_t pin_in_bytes = 0;
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};  // slot's host->device copy has left the pinned buffer
     void *team_scratch = nullptr; size_t team_scratch_bytes = 0;  // spec_k_team.hip: ring slots of every team
     void *team_sync = nullptr;    size_t team_sync_bytes = 0;     //                   tickets, ring counters, abort word    // spec_welch_psd_planar_f64: interleaved copy of the burst
     // tuning / testing knobs (spec_set_option)
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
-    int64_t opt_large_team = 1, opt_large_ring = 2;
+    int64_t opt_large_team = 1, opt_large_ring = 3, opt_large_wg = 512, opt_large_block = 0;
     int n_cu = 256;
     // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
     // them against the compute stream, created on first use
@@ -66,6 +75,14 @@ struct spec_ctx {
     int64_t opt_readahead_lines = 256, opt_render_fused = 1;
     // spec_waterfall_render: device table "pixel row of bin k" of the last (nfft, height) pair
     int32_t *sel_dev = nullptr; uint32_t sel_nfft = 0, sel_height = 0;
+};
+
+// a recording on disk (SigMfHelper.load's data file, SMH:49-94): descriptor, payload offset and size
+struct spec_recording {
+    int fd = -1;
+    uint64_t header = 0;  // core:header_bytes (SMH:60-67)
+    uint64_t bytes = 0;   // payload bytes after the header -- no 2 GiB cap (SMH:78-82)
+    std::string path;
 };
 
 static thread_local std::string g_create_err;
@@ -248,6 +265,8 @@ void spec_destroy(spec_ctx *c) {
     (void)hipFree(c->scratch);
     (void)hipFree(c->scratch2);
     (void)hipFree(c->planar);
+    if (c->pin_in) (void)hipHostFree(c->pin_in);
+    for (int i = 0; i < 2; ++i) if (c->ev_pin[i]) (void)hipEventDestroy(c->ev_pin[i]);
     (void)hipFree(c->team_scratch);
     (void)hipFree(c->team_sync);
     (void)hipFree(c->sel_dev);
@@ -281,6 +300,8 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 1 ? 1 : (value > 4 ? 4 : value);
+    else if (!strcmp(key, "large_wg")) c->opt_large_wg = value == 256 ? 256 : 512;
+    else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
     else if (!strcmp(key, "readahead_lines")) { c->opt_readahead_lines = value < 0 ? 0 : value; c->ra.n = 0; }
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
@@ -463,7 +484,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         if (team) {
             uint32_t teams_max = 0;
             const uint32_t ring = (uint32_t)c->opt_large_ring;
-            hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, nullptr, ring, nullptr, c->n_cu, &teams_max, true, c->stream);
+            hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, nullptr, ring, nullptr, c->n_cu, &teams_max, true, c->stream,
+                                               (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team query: %s", hipGetErrorString(e));
             if ((st = grow(c, &c->team_scratch, &c->team_scratch_bytes, (size_t)(teams_max ? teams_max : 1) * ring * per_line)) != SPEC_OK) return st;
             if ((st = grow(c, &c->team_sync, &c->team_sync_bytes, large_team_sync_bytes())) != SPEC_OK) return st;
@@ -476,7 +498,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             a.iq = d_first + done * (uint64_t)hop * a.bps;
             a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
             hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, c->team_scratch, (uint32_t)c->opt_large_ring,
-                                               static_cast<uint32_t *>(c->team_sync), c->n_cu, &teams_max, false, c->stream);
+                                               static_cast<uint32_t *>(c->team_sync), c->n_cu, &teams_max, false, c->stream,
+                                               (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team launch: %s", hipGetErrorString(e));
             done += nl;
             if (done < n_lines || c->opt_large_team == 2) {
@@ -582,15 +605,59 @@ static spec_status check_common(spec_ctx *c, const void *iq, const void *out, in
     return SPEC_OK;
 }
 
+// read [off, off + len) of the file into dst; holes of a sparse file and bytes past EOF read as zero
+static bool pread_all(int fd, uint8_t *dst, uint64_t len, uint64_t off) {
+    while (len) {
+        const ssize_t r = pread(fd, dst, len > (1u << 30) ? (1u << 30) : (size_t)len, (off_t)off);
+        if (r < 0) { if (errno == EINTR) continue; return false; }
+        if (r == 0) { memset(dst, 0, len); return true; }
+        dst += r; off += (uint64_t)r; len -= (uint64_t)r;
+    }
+    return true;
+}
+// the same with the range cut over a few threads: one thread copies out of the page cache at 5-10 GB/s,
+// PCIe Gen5 x16 takes 60
+static bool pread_parallel(int fd, uint8_t *dst, uint64_t len, uint64_t off) {
+    const uint64_t min_part = 8ull << 20;
+    unsigned parts = (unsigned)(len / min_part);
+    if (parts > 6) parts = 6;
+    if (parts < 2) return pread_all(fd, dst, len, off);
+    std::vector<std::thread> th;
+    std::vector<char> ok(parts, 0);
+    const uint64_t per = (len / parts + 4095) & ~4095ull;
+    for (unsigned i = 0; i < parts; ++i) {
+        const uint64_t a = (uint64_t)i * per, b = i + 1 == parts ? len : (a + per < len ? a + per : len);
+        if (a >= b) { ok[i] = 1; continue; }
+        try { th.emplace_back([=, &ok] { ok[i] = pread_all(fd, dst + a, b - a, off + a); }); }
+        catch (...) { ok[i] = pread_all(fd, dst + a, b - a, off + a); }
+    }
+    for (auto &t : th) t.join();
+    for (char k : ok) if (!k) return false;
+    return true;
+}
+static spec_status grow_pinned(spec_ctx *c, size_t need) {
+    if (c->pin_in_bytes >= need) return SPEC_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->s_in) HIP_TRY(c, hipStreamSynchronize(c->s_in));
+    if (c->pin_in) { (void)hipHostFree(c->pin_in); c->pin_in = nullptr; c->pin_in_bytes = 0; }
+    HIP_TRY(c, hipHostMalloc(&c->pin_in, need, hipHostMallocDefault));
+    c->pin_in_bytes = need;
+    for (int i = 0; i < 2; ++i)
+        if (!c->ev_pin[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_pin[i], hipEventDisableTiming));
+    return SPEC_OK;
+}
+
 extern "C" {
 
+// rec != nullptr: the input is the payload of a recording on disk (iq is ignored, iq_on_device must be 0)
 static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device, uint64_t n_bytes, uint64_t start_byte,
                                   spec_dtype dt, uint32_t nfft, uint32_t hop, uint64_t n_lines, spec_window window,
                                   spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device,
-                                  const int32_t *d_sel, uint32_t sel_row) {
+                                  const int32_t *d_sel, uint32_t sel_row, const spec_recording *rec = nullptr) {
     if (!c) return SPEC_EINVAL;
     Enter g(c);
     int log2n = 0;
+    if (rec) { iq = rec; iq_on_device = 0; n_bytes = rec->bytes; }  // iq only has to be non-null from here on
     spec_status st = check_common(c, iq, out, dt, nfft, hop, window, &log2n);
     if (st != SPEC_OK) return st;
     if (out_fmt < SPEC_OUT_DB20_F32 || out_fmt > SPEC_OUT_POW_F64) return fail(c, SPEC_EINVAL, "bad out_fmt %d", out_fmt);
@@ -651,6 +718,12 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
         if (!iq_on_device) {
             st = grow(c, &c->stage_in, &c->stage_in_bytes, in_len);
             if (st != SPEC_OK) return st;
+            if (rec) {  // file -> pinned buffer -> device
+                if ((st = grow_pinned(c, in_len)) != SPEC_OK) return st;
+                if (!pread_parallel(rec->fd, static_cast<uint8_t *>(c->pin_in), in_len, rec->header + start_byte))
+                    return fail(c, SPEC_EDEVICE, "reading %s: %s", rec->path.c_str(), strerror(errno));
+                d_in = static_cast<const uint8_t *>(c->pin_in);
+            }
             HIP_TRY(c, hipMemcpyAsync(c->stage_in, d_in, in_len, hipMemcpyHostToDevice, c->stream));
             d_in = static_cast<const uint8_t *>(c->stage_in);
         }
@@ -668,6 +741,7 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
     }
     if (n_chunks > 1) {
         if (!iq_on_device) { st = grow(c, &c->stage_in, &c->stage_in_bytes, slots * in_chunk_bytes); if (st != SPEC_OK) return st; }
+        if (rec) { st = grow_pinned(c, slots * in_chunk_bytes); if (st != SPEC_OK) return st; }
         if (!out_on_device) { st = grow(c, &c->stage_out, &c->stage_out_bytes, slots * out_chunk_bytes); if (st != SPEC_OK) return st; }
         if (!c->s_in) {
             HIP_TRY(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
@@ -737,9 +811,19 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
             d_in = static_cast<const uint8_t *>(iq) + in_off;
         } else {
             uint8_t *dst = static_cast<uint8_t *>(c->stage_in) + slot * in_chunk_bytes;
-            if (chunk >= 2) perr = hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0);  // kernels of chunk - 2 have read the slot
-            if (perr == hipSuccess)
-                perr = hipMemcpyAsync(dst, static_cast<const uint8_t *>(iq) + in_off, in_len, hipMemcpyHostToDevice, c->s_in);
+            const uint8_t *h_src = static_cast<const uint8_t *>(iq) + in_off;
+            if (rec) {  // pread the chunk into its pinned slot (free once the copy of chunk - 2 has left it)
+                uint8_t *pin = static_cast<uint8_t *>(c->pin_in) + slot * in_chunk_bytes;
+                if (chunk >= 2) perr = hipEventSynchronize(c->ev_pin[slot]);
+                if (perr == hipSuccess && !pread_parallel(rec->fd, pin, in_len, rec->header + in_off)) {
+                    pst = fail(c, SPEC_EDEVICE, "reading %s: %s", rec->path.c_str(), strerror(errno));
+                    break;
+                }
+                h_src = pin;
+            }
+            if (perr == hipSuccess && chunk >= 2) perr = hipStreamWaitEvent(c->s_in, c->ev_done[slot], 0);  // kernels of chunk - 2 have read the slot
+            if (perr == hipSuccess) perr = hipMemcpyAsync(dst, h_src, in_len, hipMemcpyHostToDevice, c->s_in);
+            if (perr == hipSuccess && rec) perr = hipEventRecord(c->ev_pin[slot], c->s_in);
             if (perr == hipSuccess) perr = hipEventRecord(c->ev_in[slot], c->s_in);
             if (perr == hipSuccess) perr = hipStreamWaitEvent(c->stream, c->ev_in[slot], 0);
             if (perr != hipSuccess) break;
@@ -797,6 +881,74 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
                            spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device) {
     return waterfall_impl(c, iq, iq_on_device, n_bytes, start_byte, dt, nfft, hop, n_lines, window, out_fmt, eof_fill, out,
                           out_on_device, nullptr, 0);
+}
+
+// ---- recordings on disk (SURVEY 8f "next" #3; SigMfHelper.java:49-94) ---------------------------------
+spec_status spec_open_recording(spec_ctx *c, const char *data_path, uint64_t header_bytes, spec_recording **out) {
+    if (!c) return SPEC_EINVAL;
+    Enter g(c);
+    if (!data_path || !out) return fail(c, SPEC_EINVAL, "spec_open_recording: null argument");
+    *out = nullptr;
+    const int fd = open(data_path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(c, SPEC_EINVAL, "cannot open %s: %s", data_path, strerror(errno));
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        close(fd);
+        return fail(c, SPEC_EINVAL, "%s is not a regular file", data_path);
+    }
+    spec_recording *r = new (std::nothrow) spec_recording;
+    if (!r) { close(fd); return fail(c, SPEC_ENOMEM, "out of host memory"); }
+    r->fd = fd;
+    r->header = header_bytes;
+    const uint64_t size = (uint64_t)sb.st_size;
+    r->bytes = size > header_bytes ? size - header_bytes : 0;  // SMH:74-76: max(0, channelSize - headerBytes)
+    try { r->path = data_path; } catch (...) {}
+    *out = r;
+    return SPEC_OK;
+}
+
+uint64_t spec_recording_bytes(const spec_recording *rec) { return rec ? rec->bytes : 0; }
+
+void spec_close_recording(spec_recording *rec) {
+    if (!rec) return;
+    if (rec->fd >= 0) close(rec->fd);
+    delete rec;
+}
+
+spec_status spec_waterfall_recording(spec_ctx *c, const spec_recording *rec, uint64_t start_byte, spec_dtype dt,
+                                     uint32_t nfft, uint32_t hop, uint64_t n_lines, spec_window window,
+                                     spec_out_fmt out_fmt, double eof_fill, void *out, int out_on_device) {
+    if (!c) return SPEC_EINVAL;
+    if (!rec) return fail(c, SPEC_EINVAL, "null recording");
+    return waterfall_impl(c, nullptr, 0, 0, start_byte, dt, nfft, hop, n_lines, window, out_fmt, eof_fill, out, out_on_device,
+                          nullptr, 0, rec);
+}
+
+// computeMagnitudes with the 64-bit offset the reference cannot express (SS:33 takes an int startByte,
+// MC:985 casts to int): one slice of a recording of any size, fp64 pipeline
+spec_status spec_compute_magnitudes_recording(spec_ctx *c, const spec_recording *rec, uint64_t start_byte, uint32_t nfft,
+                                              const char *datatype, int big_endian, double *out) {
+    if (!c) return SPEC_EINVAL;
+    Enter g(c);
+    if (!rec || !out || !datatype) return fail(c, SPEC_EINVAL, "null argument");
+    if (nfft == 0 || (nfft & (nfft - 1)) != 0) return fail(c, SPEC_EINVAL, "nfft = %u is not a power of two", nfft);
+    spec_dtype dt = spec_dtype_from_sigmf(datatype);
+    switch (dt) {
+    case SPEC_DT_CI16_LE: case SPEC_DT_CI16_BE: dt = big_endian ? SPEC_DT_CI16_BE : SPEC_DT_CI16_LE; break;
+    case SPEC_DT_CF32_LE: case SPEC_DT_CF32_BE: dt = big_endian ? SPEC_DT_CF32_BE : SPEC_DT_CF32_LE; break;
+    case SPEC_DT_CF64_LE: case SPEC_DT_CF64_BE: dt = big_endian ? SPEC_DT_CF64_BE : SPEC_DT_CF64_LE; break;
+    default: break;
+    }
+    if (kind_of(dt, c->flags) == K_ZERO) {  // SS:60-63: nothing is read, flat 20 log10(1e-10)
+        for (uint32_t i = 0; i < nfft; ++i) out[i] = -200.0;
+        return SPEC_OK;
+    }
+    const uint64_t span = (uint64_t)nfft * spec_bytes_per_sample(dt);
+    if (start_byte > rec->bytes || span > rec->bytes - start_byte)
+        return fail(c, SPEC_ERANGE, "IndexOutOfBounds: bytes [%llu, +%llu) of %llu", (unsigned long long)start_byte,
+                    (unsigned long long)span, (unsigned long long)rec->bytes);
+    return waterfall_impl(c, nullptr, 0, 0, start_byte, dt, nfft, nfft, 1, SPEC_WIN_RECT, SPEC_OUT_DB20_F64, -150.0, out, 0,
+                          nullptr, 0, rec);
 }
 
 spec_status spec_compute_magnitudes(spec_ctx *c, const void *buffer, uint64_t capacity, int64_t start_byte,
@@ -974,7 +1126,7 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         const uint32_t n_slabs = wgs * sub;
         st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)n_psd * n_slabs * nfft * sizeof(float));
         if (st != SPEC_OK) return st;
-        a.partial = static_cast<float *>(c->scratch);
+        a.partial = c->scratch;
         float *d_out = psd_out;
         if (!out_on_device) {
             st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * sizeof(float));
@@ -984,7 +1136,7 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         hipError_t e = launch_v2_welch(a, log2n, (uint32_t)run, wgs, c->stream);
         if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch launch: %s", hipGetErrorString(e));
         const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
-        e = launch_welch_finalize(a.partial, n_psd, n_slabs, nfft, norm, db, d_out, c->stream);
+        e = launch_welch_finalize(a.partial, 0, n_psd, n_slabs, nfft, norm, db, d_out, 0, c->stream);
         if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch finalize launch: %s", hipGetErrorString(e));
         if (!out_on_device) {
             HIP_TRY(c, hipMemcpyAsync(psd_out, d_out, (size_t)n_psd * nfft * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -996,8 +1148,47 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
             for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
         return SPEC_OK;
     }
-    // Fallback for what the packed family does not take (cf64, big-endian files, nfft < 256 or
-    // > 16384): |X|^2 lines of the spectrogram path (fp64 for cf64) summed per bin in a fixed order.
+    if (f64 && !c->opt_force_generic && a.kind != K_ZERO && v3d_applicable(log2n, a.kind, n_seg, hop)) {
+        // fp64 member of the family (the dialog's calculatePsdWelch call, cf64 recordings, fp64 output): |X|^2 summed
+        // in registers, one double slab per sub-line, the same finalize -- one launch + finalize for any batch
+        st = get_twiddles(c, log2n, true, &a.tw);
+        if (st != SPEC_OK) return st;
+        st = get_window(c, log2n, true, window, &a.win, &s1, &s2, /*table_for_rect=*/true);
+        if (st != SPEC_OK) return st;
+        const uint32_t sub = (uint32_t)v3d_lpw(log2n);
+        uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg
+                                                : ((uint64_t)n_seg * n_psd) / ((uint64_t)c->n_cu * 8 * sub);
+        if (run < 1) run = 1;
+        if (run > 64) run = 64;
+        if (run > n_seg) run = n_seg;
+        const uint32_t wgs = (uint32_t)((n_seg + run * sub - 1) / (run * sub));
+        const uint32_t n_slabs = wgs * sub;
+        st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)n_psd * n_slabs * nfft * sizeof(double));
+        if (st != SPEC_OK) return st;
+        a.partial = c->scratch;
+        void *d_out = psd_out_v;
+        if (!out_on_device) {
+            st = grow(c, &c->stage_out, &c->stage_out_bytes, (size_t)n_psd * nfft * out_esz);
+            if (st != SPEC_OK) return st;
+            d_out = c->stage_out;
+        }
+        hipError_t e = launch_v3d_welch(a, log2n, (uint32_t)run, wgs, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "fp64 welch launch: %s", hipGetErrorString(e));
+        const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
+        e = launch_welch_finalize(a.partial, 1, n_psd, n_slabs, nfft, norm, db, d_out, out_f64, c->stream);
+        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch finalize launch: %s", hipGetErrorString(e));
+        if (!out_on_device) {
+            HIP_TRY(c, hipMemcpyAsync(psd_out_v, d_out, (size_t)n_psd * nfft * out_esz, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else if (!iq_on_device) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (freq_out)
+            for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
+        return SPEC_OK;
+    }
+    // Fallback for what neither family takes (nfft < 256, 16384 points and more in fp64, 32768 and more in
+    // fp32): |X|^2 lines of the spectrogram path (fp64 for cf64) summed per bin in a fixed order.
     const spec_out_fmt pfmt = f64 ? SPEC_OUT_POW_F64 : SPEC_OUT_POW_F32;
     const size_t esz = f64 ? 8 : 4;
     uint64_t seg_chunk = (128ull << 20) / ((uint64_t)nfft * esz);

@@ -35,7 +35,7 @@ struct WelchArgs {
     uint32_t hop, bps;
     int kind, be;
     const void *tw, *win;
-    float *partial;             // [n_psd][slabs][N] unshifted power sums (fp32)
+    void *partial;              // [n_psd][slabs][N] unshifted power sums (fp32; fp64 for launch_v3d_welch)
 };
 
 int plan_lpw(int log2n);  // lines a workgroup transforms concurrently
@@ -60,7 +60,7 @@ size_t large_team_sync_bytes();
 uint32_t large_team_abort_word();
 hipError_t launch_spectro_team(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2, void *scratch,
                                uint32_t ring, uint32_t *sync, int n_cu, uint32_t *teams_max, bool query_only,
-                               hipStream_t s);
+                               hipStream_t s, int wg = 512, uint32_t block = 0);
 
 // packed-fp32 family (spec_v2.h): every LDS-resident size, cf32/ci16/cu8/ci8 little endian
 bool v2_applicable(int log2n, int kind, int be, int out_fmt, uint64_t n_lines, uint32_t hop);
@@ -75,8 +75,12 @@ hipError_t launch_v2_spectro_sel(const WfArgs &w, int log2n, uint32_t run, const
 hipError_t launch_v2_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t wgs_per_unit, hipStream_t s);
 
 hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);
-hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs,
-                                 uint32_t nfft, double norm, int db, float *psd_out, hipStream_t s);
+// slabs_f64 / out_f64: element type of the slabs / of psd_out
+hipError_t launch_welch_finalize(const void *partial, int slabs_f64, uint32_t n_psd, uint32_t n_slabs,
+                                 uint32_t nfft, double norm, int db, void *psd_out, int out_f64, hipStream_t s);
+// fp64 member: double slabs (spec_v3d.h MODE 1); v3d_lpw = sub-lines per workgroup of that family
+int v3d_lpw(int log2n);
+hipError_t launch_v3d_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t wgs_per_unit, hipStream_t s);
 // fallback Welch: acc[k] += sum over n lines of fftshifted power lines (float or double);
 // then scale / dB into psd_out
 hipError_t launch_welch_accum(const void *lines, int lines_f64, uint64_t n, uint32_t nfft, double *acc, hipStream_t s);

@@ -5,9 +5,9 @@
 // launches with the [n2][k1] intermediate in HBM: three bytes moved per algorithmic byte.  Here ONE persistent
 // launch keeps that intermediate inside one XCD's 4 MiB L2:
 //
-//   * the launch is sized to be fully resident (<= 2 workgroups of 256 threads per CU).  Every workgroup reads
+//   * the launch is sized to be fully resident (512 threads per CU: one workgroup of 512 or two of 256).  Every workgroup reads
 //     the id of the XCD it actually runs on (HW_REG_XCC_ID) and takes a ticket on that XCD; after a one-time
-//     registration wait the workgroups of one XCD form TEAMS of 2 NT members (NT = N / 2048 tiles per line and
+//     registration wait the workgroups of one XCD form TEAMS of 2 NT members (NT = N / (8 WG) tiles per line and
 //     step), NT "column" workgroups and NT "row" workgroups.  Teams are built from the XCD ids the hardware
 //     reports, never from blockIdx, so the result does not depend on how the dispatcher places workgroups --
 //     a different placement only changes who is in which team; workgroups left over on an XCD exit.
@@ -35,15 +35,15 @@ namespace specgpu {
 
 namespace {
 
-constexpr int TEAM_WG = 256;  // threads per workgroup
 constexpr int TE = 8;         // points per thread
 constexpr int TEAM_RING_MAX = 4;
 constexpr long long TEAM_SPIN_LIMIT = 200000000ll;  // wall_clock64 ticks (100 MHz): 2 s
 
 // sub-transform of 2^L points by T = 2^L / 8 threads, radices 8 x 8 x (M / 64)
-template <int L> struct TP {
+template <int L, int WG> struct TP {
     static_assert(L == 7 || L == 8, "sub-transforms of 128 or 256 points");
-    static constexpr int M = 1 << L, T = M / TE, C = TEAM_WG / T;  // C sub-transforms (columns / rows) per tile
+    static_assert(WG == 256 || WG == 512, "workgroups of 256 or 512 threads");
+    static constexpr int M = 1 << L, T = M / TE, C = WG / T;  // C sub-transforms (columns / rows) per tile
     static constexpr int R2 = M / 64, S2 = TE / R2;
     static constexpr int SL = M + 1;  // LDS line stride in elements (odd: adjacent lines start in adjacent slots)
 };
@@ -70,6 +70,7 @@ struct TeamArgs {
     void *out;
     int out_fmt;
     uint32_t ring;
+    uint32_t block;         // lines per block of the block-cyclic deal of lines to teams (0: one contiguous range each)
     uint32_t *sync;
 };
 
@@ -105,14 +106,14 @@ __device__ __forceinline__ bool team_wait(const uint32_t *ctr, uint32_t target, 
 template <typename R> __device__ __forceinline__ void ctw(cx<R> &u, const cx<R> w) { u = cmul(u, w); }
 
 // passes 1 and 2 of the 8 x 8 x R2 plan on the registers of butterfly index t (pass 0 is a bare dft8)
-template <typename R, int L> __device__ __forceinline__ void pass1(cx<R> (&v)[TE], int t, const cx<R> *tab) {
+template <typename R, int L, int WG> __device__ __forceinline__ void pass1(cx<R> (&v)[TE], int t, const cx<R> *tab) {
     const int k = t & 7;
 #pragma unroll
-    for (int r = 1; r < 8; ++r) ctw(v[r], tab[r * k * (TP<L>::M / 64)]);
+    for (int r = 1; r < 8; ++r) ctw(v[r], tab[r * k * (TP<L, WG>::M / 64)]);
     dft8(v);
 }
-template <typename R, int L> __device__ __forceinline__ void pass2(cx<R> (&v)[TE], int t, const cx<R> *tab) {
-    using P = TP<L>;
+template <typename R, int L, int WG> __device__ __forceinline__ void pass2(cx<R> (&v)[TE], int t, const cx<R> *tab) {
+    using P = TP<L, WG>;
 #pragma unroll
     for (int s = 0; s < P::S2; ++s) {
         const int k = (t + s * P::T) & 63;
@@ -136,27 +137,59 @@ template <typename R> __device__ __forceinline__ void xstore1(const cx<R> (&v)[T
 #pragma unroll
     for (int r = 0; r < 8; ++r) line[j + 8 * r] = v[r];
 }
-template <typename R, int L> __device__ __forceinline__ void xload(cx<R> (&v)[TE], int t, const cx<R> *line) {
+template <typename R, int L, int WG> __device__ __forceinline__ void xload(cx<R> (&v)[TE], int t, const cx<R> *line) {
 #pragma unroll
-    for (int m = 0; m < TE; ++m) v[m] = line[t + m * TP<L>::T];
+    for (int m = 0; m < TE; ++m) v[m] = line[t + m * TP<L, WG>::T];
 }
 
-typedef uint32_t tu32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t tu32x2 __attribute__((ext_vector_type(2)));
-// one cx<R> from the ring slot with an sc1 load: served by the XCD's L2, never by this CU's L1
-template <typename R> __device__ __forceinline__ cx<R> ld_slot(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    constexpr int SC1 = 16;
-    if constexpr (sizeof(R) == 8) {
-        const tu32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, SC1);
-        return cx<R>{__longlong_as_double((long long)(((uint64_t)u.y << 32) | u.x)),
-                     __longlong_as_double((long long)(((uint64_t)u.w << 32) | u.z))};
-    } else {
-        const tu32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, SC1);
-        return cx<R>{__uint_as_float(u.x), __uint_as_float(u.y)};
-    }
+// ---- loads the compiler does not track ------------------------------------------------------------------
+// Both sides keep loads in flight ACROSS loop iterations and behind younger stores.  hipcc inserts its own
+// s_waitcnt for every load it knows; for a result that is used one iteration later it cannot count the
+// instructions in between and waits for vmcnt(0) -- which, vmcnt being one in-order counter for loads and
+// stores, also waits for every store issued since (the row side then sat out the HBM write latency of its own
+// output once per line).  Loads written as inline assembly are invisible to that pass, but a load with a VGPR
+// destination is not safe either: the compiler believes the value is there at ";;#ASMEND" and resolved the
+// loops' phi nodes by copying those registers right behind the load -- copying what had not arrived (wrong
+// lines; tying the operands "+v" did not stop it).  So the pipelined loads are LDS-DMA (global_load_lds: no
+// register destination, nothing for the compiler to copy): every wave lands its loads in a private 1 KiB-per-
+// instruction strip of LDS (lane l at byte 16 l), waits with vm_wait<N> -- "all but the N youngest vector-memory
+// instructions of this wave are done", N a LOWER bound of the instructions issued since -- and reads its own
+// lanes back with ds_read_b128.  The waits carry a "memory" clobber: no LDS read moves above them.  Only the
+// fp64 kernels are pipelined this way (LDS-DMA moves 4 or 16 bytes per lane; a cx<float> is 8).
+#ifdef SPEC_TEAM_STRICT_WAITS  // debugging aid: every counted wait becomes vmcnt(0)
+#define VM_N(N) 0
+#else
+#define VM_N(N) (N)
+#endif
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_N(N)) : "memory"); }
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byte address of a pointer into shared memory
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+// 16 bytes per lane from gsrc (per lane) to LDS lds_dst + 16 * lane (lds_dst wave-uniform).  M0 carries the LDS
+// base; it is the compiler's register, so it is saved and restored inside the statement.  The leading
+// lgkmcnt(0): this wave's earlier reads of the strip have left the LDS queue before the strip is rewritten.
+// POLICY 0: nt (the recording, read once); 1: sc1 (the ring slot: L2, never this CU's L1)
+template <int POLICY> __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    if constexpr (POLICY == 0)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// one counter word (lane 0 of the calling branch) to LDS lds_dst, sc1
+__device__ __forceinline__ void glds4_sc1(const uint32_t *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// one cx<R> of the recording, read once: non-temporal
+// the same load as the compiler knows it (plain forms)
 template <typename R> __device__ __forceinline__ cx<R> ld_stream(const uint8_t *p) {
     if constexpr (sizeof(R) == 8) {
         typedef double d2 __attribute__((ext_vector_type(2)));
@@ -168,19 +201,89 @@ template <typename R> __device__ __forceinline__ cx<R> ld_stream(const uint8_t *
         return cx<R>{u.x, u.y};
     }
 }
+typedef uint32_t tu32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t tu32x2 __attribute__((ext_vector_type(2)));
+// one cx<R> from the ring slot with an sc1 load the compiler knows: served by the XCD's L2, never by this CU's L1
+template <typename R> __device__ __forceinline__ cx<R> ld_slot(__amdgpu_buffer_rsrc_t rs, int voff) {
+    constexpr int SC1 = 16;
+    if constexpr (sizeof(R) == 8) {
+        const tu32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, SC1);
+        return cx<R>{__longlong_as_double((long long)(((uint64_t)u.y << 32) | u.x)),
+                     __longlong_as_double((long long)(((uint64_t)u.w << 32) | u.z))};
+    } else {
+        const tu32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, SC1);
+        return cx<R>{__uint_as_float(u.x), __uint_as_float(u.y)};
+    }
+}
 
-template <typename R, int L1, int L2, bool DIRECT>
-__global__ __launch_bounds__(TEAM_WG, 2) void large_team_kernel(const TeamArgs a) {
-    using PA = TP<L1>;
-    using PB = TP<L2>;
+template <typename R> __device__ __forceinline__ void st_slot(cx<R> *p, cx<R> v) {  // plain store: stays in L2
+    if constexpr (sizeof(R) == 8) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<d2 *>(p) = d2{v.x, v.y};
+    } else {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f2 *>(p) = f2{v.x, v.y};
+    }
+}
+
+#ifdef SPEC_ABL_TEAM_NOSTORE
+constexpr int TEAM_NST = 0;
+#else
+constexpr int TEAM_NST = TE;  // output stores per thread and line: one instruction per bin, every format
+#endif
+
+// one bin of the result (SS:76-82), non-temporal: written once, never read by this launch
+template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *out, uint64_t idx, cx<R> z, const double *dbt) {
+#ifdef SPEC_ABL_TEAM_NOSTORE
+    if (z.x == (R)1.2345e-30) static_cast<float *>(out)[idx & 1023] = 0.0f;  // never true: keeps z alive
+#elif defined(SPEC_ABL_TEAM_NOEPI)
+    if constexpr (FMT >= OUT_DB20_F64) __builtin_nontemporal_store((double)z.x, static_cast<double *>(out) + idx);
+    else __builtin_nontemporal_store((float)z.x, static_cast<float *>(out) + idx);
+#else
+    if constexpr (sizeof(R) == 4) {
+        const float r = FMT == OUT_DB20_F32 ? db20(z) : z.x * z.x + z.y * z.y;
+        __builtin_nontemporal_store(r, static_cast<float *>(out) + idx);
+    } else {
+        const bool dbf = FMT == OUT_DB20_F32 || FMT == OUT_DB20_F64;
+        const double r = dbf ? db20_tab(z, dbt) : __builtin_fma(z.x, z.x, z.y * z.y);
+        if constexpr (FMT >= OUT_DB20_F64) __builtin_nontemporal_store(r, static_cast<double *>(out) + idx);
+        else __builtin_nontemporal_store((float)r, static_cast<float *>(out) + idx);
+    }
+#endif
+}
+
+// Dynamic LDS of one workgroup.  fp64 (pipelined loads): 256 bytes for the polled counter word, then the landing
+// strips -- WG / 64 waves x TE instructions x 1 KiB -- FIRST, so that every strip's base address fits the 16
+// bits of M0 that are certain to carry it; then line buffers + sub-transform table (MAIN, in cx<R> elements).
+template <typename R, int L1, int L2, int WG> struct TeamLds {
+    static constexpr size_t A = (size_t)TP<L1, WG>::C * TP<L1, WG>::SL + TP<L1, WG>::M;
+    static constexpr size_t B = (size_t)TP<L2, WG>::C * TP<L2, WG>::SL + TP<L2, WG>::M;
+    static constexpr size_t MAIN = A > B ? A : B;
+    static constexpr bool PIPE = sizeof(R) == 8;
+    static constexpr size_t LAND_BYTES = PIPE ? 256 + (size_t)(WG / 64) * TE * 1024 : 0;
+    static constexpr size_t BYTES = LAND_BYTES + MAIN * sizeof(cx<R>);
+    // the last strip starts at LAND_BYTES - 1024 behind the kernel's static __shared__ words (< 768 bytes)
+    static_assert(LAND_BYTES == 0 || LAND_BYTES - 1024 + 767 <= 65535, "strip bases must stay below 64 KiB");
+};
+
+// HALF: hop == N / 2 (BASELINE's 50 % overlap): the lower half of line i + 1 is the upper half of line i and stays
+// in registers.  A template parameter because the pipelined column loop's waits count its load instructions.
+template <typename R, int L1, int L2, bool DIRECT, bool HALF, int WG>
+__global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
+    using PA = TP<L1, WG>;
+    using PB = TP<L2, WG>;
+    using LD = TeamLds<R, L1, L2, WG>;
     constexpr int N1 = PA::M, N2 = PB::M, N = N1 * N2;
-    constexpr uint32_t NT = N / (TEAM_WG * TE);  // tiles per line and step
+    constexpr uint32_t NT = N / (WG * TE);  // tiles per line and step
     static_assert(N2 / PA::C == (int)NT && N1 / PB::C == (int)NT, "tile counts of the two steps match");
     constexpr uint32_t TEAM = 2 * NT;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    constexpr int NEWH = TE / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_flag;
+    __shared__ int s_flag, s_next;
     __shared__ uint32_t s_info[4];
-    cx<R> *lds = reinterpret_cast<cx<R> *>(smem);
+    __shared__ double s_dbt[64];
+    cx<R> *lds = reinterpret_cast<cx<R> *>(smem + TeamLds<R, L1, L2, WG>::LAND_BYTES);  // line buffers + table
     const int tid = threadIdx.x;
     uint32_t *sync = a.sync;
 
@@ -194,6 +297,7 @@ __global__ __launch_bounds__(TEAM_WG, 2) void large_team_kernel(const TeamArgs a
         s_info[0] = xcc;
         s_info[1] = ticket;
     }
+    if (tid < 64) s_dbt[tid] = DB20_TAB[tid];
     __syncthreads();
     if (!team_wait(sync + TS_TOTAL, gridDim.x, sync, &s_flag)) return;
     // everybody has registered: the tickets per XCD are final
@@ -207,78 +311,66 @@ __global__ __launch_bounds__(TEAM_WG, 2) void large_team_kernel(const TeamArgs a
             teams_total += t;
         }
         const uint32_t local_team = ticket / TEAM;
-        s_info[2] = local_team < mine ? teams_before + local_team : 0xFFFFFFFFu;  // left over on this XCD: no team
+        s_info[2] = local_team < mine ? teams_before + local_team : NONE;  // left over on this XCD: no team
         s_info[3] = teams_total;
         if (teams_total == 0 || teams_total > TEAM_MAX_TEAMS)  // nobody could form a team: the host falls back
             __hip_atomic_store(sync + TS_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const uint32_t team = s_info[2], n_teams = s_info[3], member = s_info[1] % TEAM;
-    if (team == 0xFFFFFFFFu || n_teams == 0 || n_teams > TEAM_MAX_TEAMS) return;
-    const uint32_t line_first = (uint32_t)((uint64_t)a.n_lines * team / n_teams);
-    const uint32_t line_end = (uint32_t)((uint64_t)a.n_lines * (team + 1) / n_teams);
-    const uint32_t my_lines = line_end - line_first;
+    if (team == NONE || n_teams == 0 || n_teams > TEAM_MAX_TEAMS) return;
+    // Which lines are this team's.  block == 0: one contiguous range per team.  Otherwise blocks of `block`
+    // consecutive lines are dealt to the teams in turn: at any moment the teams then work within a few MiB of
+    // each other instead of at equal offsets in regions 2^k bytes apart (the same HBM channels and banks for
+    // every team), and a team still walks consecutive lines inside a block (the register reuse of 50 % overlap).
+    const uint32_t blk = a.block;
+    uint32_t line_first = 0, my_lines;
+    if (blk == 0) {
+        line_first = (uint32_t)((uint64_t)a.n_lines * team / n_teams);
+        my_lines = (uint32_t)((uint64_t)a.n_lines * (team + 1) / n_teams) - line_first;
+    } else {
+        const uint32_t nb = (a.n_lines + blk - 1) / blk;
+        const uint32_t mine = team < nb ? (nb - team + n_teams - 1) / n_teams : 0;
+        my_lines = mine * blk;
+        if (mine && team + (mine - 1) * n_teams == nb - 1) my_lines -= nb * blk - a.n_lines;  // the last block may be short
+    }
+    auto line_of = [&](uint32_t i) -> uint32_t {  // the i-th line of this team
+        return blk ? ((i / blk) * n_teams + team) * blk + i % blk : line_first + i;
+    };
+    auto follows = [&](uint32_t i) -> bool {  // is the team's i-th line the recording's next line after its (i-1)-th?
+        return blk == 0 || i % blk != 0;
+    };
     cx<R> *slots = static_cast<cx<R> *>(a.scratch) + (uint64_t)team * a.ring * N;
     uint32_t *ring = sync + TS_RING + team * (TEAM_RING_MAX * 32);  // slot s: doneA at 32 s, doneB at 32 s + 16
     const cx<double> *__restrict__ twn = static_cast<const cx<double> *>(a.twn);
+    if (my_lines == 0) return;
+    // landing strips of the pipelined loads (fp64): this wave's strip m at land_addr + 1024 m, own lane at [64 m + lane]
+    const uint32_t wave = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63;
+    uint32_t *pland = reinterpret_cast<uint32_t *>(smem);
+    cx<R> *land = reinterpret_cast<cx<R> *>(smem + 256 + (size_t)wave * TE * 1024);
+    const uint32_t land_addr = __builtin_amdgcn_readfirstlane(lds_addr(land));
+    const uint32_t pland_addr = __builtin_amdgcn_readfirstlane(lds_addr(pland));
+    (void)land_addr; (void)pland_addr; (void)lane;
 
     if (member < NT) {
         // ================= column side: tile of C columns, N1-point transforms over n1 =====================
+#ifdef SPEC_ABL_TEAM_NOA
+        return;
+#endif
         const uint32_t c0 = member * PA::C;
         const int q0 = tid % PA::C, t0 = tid / PA::C;  // loads: columns fastest (contiguous samples)
         const int t1 = tid % PA::T, q1 = tid / PA::T;  // stores: k1 fastest (contiguous intermediate)
         cx<R> *tab = lds + (size_t)PA::C * PA::SL;
-        for (int e = tid; e < N1; e += TEAM_WG) tab[e] = static_cast<const cx<R> *>(a.tw1)[e];
-        const bool half = (uint64_t)a.hop * 2 == (uint64_t)N;  // uniform: 50 % overlap
+        for (int e = tid; e < N1; e += WG) tab[e] = static_cast<const cx<R> *>(a.tw1)[e];
         const R *__restrict__ win = static_cast<const R *>(a.win);
-        auto load_rows = [&](uint32_t line, cx<R> (&x)[TE], auto first_tag) {
-            constexpr int FIRST = decltype(first_tag)::value;
-            const uint8_t *src = a.iq + (uint64_t)line * a.hop * a.bps;
-#pragma unroll
-            for (int m = FIRST; m < TE; ++m) {
-                const uint32_t n = (uint32_t)(t0 + m * PA::T) * N2 + c0 + q0;
-                if constexpr (DIRECT) x[m] = ld_stream<R>(src + (uint64_t)n * sizeof(cx<R>));
-                else x[m] = decode_sample<R>(src + (uint64_t)n * a.bps, a.kind, a.be != 0);
-            }
-        };
-        cx<R> nxt[TE];
-        if (my_lines) load_rows(line_first, nxt, std::integral_constant<int, 0>{});
-        __syncthreads();  // table visible
         // inter-step twiddle W_N^(n2 k1), k1 = t1 + m T: W^(n2 t1) (W^(n2 T))^m, recurrence in fp64
         const uint32_t n2 = c0 + q1;
         const cx<double> w0 = twn[n2 * (uint32_t)t1], wstep = twn[n2 * (uint32_t)PA::T];
-        for (uint32_t i = 0; i < my_lines; ++i) {
-            const uint32_t line = line_first + i, slot = i % a.ring, round = i / a.ring;
-            cx<R> v[TE];
-#pragma unroll
-            for (int m = 0; m < TE; ++m) v[m] = nxt[m];
-            if (i + 1 < my_lines) {  // the next line's rows stay in flight behind this FFT
-                if (half) {
-#pragma unroll
-                    for (int m = 0; m < TE / 2; ++m) nxt[m] = nxt[m + TE / 2];
-                    load_rows(line + 1, nxt, std::integral_constant<int, TE / 2>{});
-                } else {
-                    load_rows(line + 1, nxt, std::integral_constant<int, 0>{});
-                }
-            }
-            if (win) {
-#pragma unroll
-                for (int m = 0; m < TE; ++m) {
-                    const R w = win[(uint32_t)(t0 + m * PA::T) * N2 + c0 + q0];
-                    v[m].x *= w;
-                    v[m].y *= w;
-                }
-            }
-            dft8(v);
-            xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
-            __syncthreads();
-            xload<R, L1>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here
-            __syncthreads();
-            pass1<R, L1>(v, t1, tab);
-            xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
-            __syncthreads();
-            xload<R, L1>(v, t1, lds + (size_t)q1 * PA::SL);
-            pass2<R, L1>(v, t1, tab);
+        // rest of one line behind the first exchange: pass 2 and the inter-step twiddle
+        auto finish = [&](cx<R> (&v)[TE]) {
+#ifndef SPEC_ABL_TEAM_NOFFT
+            pass2<R, L1, WG>(v, t1, tab);
+#endif
             cx<double> w = w0;
 #pragma unroll
             for (int m = 0; m < TE; ++m) {
@@ -286,81 +378,320 @@ __global__ __launch_bounds__(TEAM_WG, 2) void large_team_kernel(const TeamArgs a
                 v[m] = cx<R>{(R)z.x, (R)z.y};
                 w = cmul(w, wstep);
             }
-            // the slot is free once the row side has read its previous line (the barriers inside also
-            // separate this line's last LDS reads from the next line's first LDS writes)
-            if (!team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
-            cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
+        };
+        if constexpr (DIRECT && LD::PIPE) {
+            if (win == nullptr) {
+                // ---- pipelined form: samples are cx<double> in memory, no window ----------------------------------
+                // `cur` (registers) holds line i.  The rows of line i + 1 that `cur` lacks (at 50 % overlap the upper
+                // half: the lower half of line i + 1 is the upper half of line i) land in the strips, requested one
+                // whole line earlier and issued BEHIND line i - 1's stores, so that the counted wait for those stores
+                // leaves them in flight.  Per line: [poll slot of line i + 1] [stores of line i] [loads of line i + 2].
+                constexpr int NLD = HALF ? NEWH : TE;  // LOWER bound of the loads issued behind a line's stores
+                auto issue = [&](uint32_t line, auto first_tag) {
+                    constexpr int FIRST = decltype(first_tag)::value;
+                    const uint8_t *src = a.iq + (uint64_t)line * a.hop * sizeof(cx<R>);
 #pragma unroll
-            for (int m = 0; m < TE; ++m) dst[t1 + m * PA::T] = v[m];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int m = FIRST; m < TE; ++m)
+                        glds16<0>(src + (uint64_t)((uint32_t)(t0 + m * PA::T) * N2 + c0 + q0) * sizeof(cx<R>), land_addr + 1024u * m);
+                };
+                // at the start of a block of lines all eight rows are requested (the counted wait then also waits for
+                // the first four of them, once per block)
+                auto issue_next = [&](uint32_t i_next) {
+                    const uint32_t ic = i_next < my_lines ? i_next : my_lines - 1;  // tail: a valid line again, unused
+                    if (HALF && follows(ic)) issue(line_of(ic), std::integral_constant<int, NEWH>{});
+                    else issue(line_of(ic), std::integral_constant<int, 0>{});
+                };
+                cx<R> cur[TE];
+                issue(line_of(0), std::integral_constant<int, 0>{});
+                vm_wait<0>();  // first line: nothing to overlap with yet
+#pragma unroll
+                for (int m = 0; m < TE; ++m) cur[m] = land[64 * m + lane];
+                issue_next(1);
+                __syncthreads();  // table visible
+                uint32_t pending = NONE;  // ring slot whose stores are issued but not yet announced
+                for (uint32_t i = 0; i < my_lines; ++i) {
+                    const uint32_t slot = i % a.ring, round = i / a.ring;
+                    cx<R> v[TE];
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) v[m] = cur[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    dft8(v);
+#endif
+                    xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
+                    // the previous line's stores (and the poll before them) have had this long: wait for them, not
+                    // for the NLD loads issued behind them, then announce that line behind the exchange's barrier
+                    vm_wait<NLD>();
+                    __syncthreads();
+                    if (tid == 0 && pending != NONE)
+                        __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here
+                    __syncthreads();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    pass1<R, L1, WG>(v, t1, tab);
+#endif
+                    xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
+                    // was the slot free when the poll was taken?  (first lines: nobody has used it yet)
+                    if (tid == 0) s_flag = round == 0 || (pending != NONE && (int32_t)(pland[0] - NT * round) >= 0);
+                    __syncthreads();
+                    const bool slot_free = s_flag != 0;
+                    xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
+                    finish(v);
+                    // cur <- line i + 1: its rows were requested a whole line ago (behind the last line: unused)
+                    vm_wait<0>();
+                    if (HALF && follows(i + 1 < my_lines ? i + 1 : my_lines - 1)) {
+#pragma unroll
+                        for (int m = 0; m < NEWH; ++m) { cur[m] = cur[m + NEWH]; cur[m + NEWH] = land[64 * (m + NEWH) + lane]; }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < TE; ++m) cur[m] = land[64 * m + lane];
+                    }
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                    if (!slot_free && !team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
+#endif
+                    if (tid == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, pland_addr);  // before the stores
+                    cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) st_slot<R>(dst + t1 + m * PA::T, v[m]);
+                    asm volatile("" ::: "memory");  // the loads below stay behind the stores above
+                    pending = slot;
+                    issue_next(i + 2);
+                    __syncthreads();  // this line's last LDS reads | the next line's first LDS writes
+                }
+                vm_wait<0>();
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        // ---- plain form (fp32, decoded formats, windows): one line of input ahead, every line announced at once ----
+        {
+            constexpr bool half = HALF;
+            auto load_rows = [&](uint32_t line, cx<R> (&x)[TE], auto first_tag) {
+                constexpr int FIRST = decltype(first_tag)::value;
+                const uint8_t *src = a.iq + (uint64_t)line * a.hop * a.bps;
+#pragma unroll
+                for (int m = FIRST; m < TE; ++m) {
+                    const uint32_t n = (uint32_t)(t0 + m * PA::T) * N2 + c0 + q0;
+                    if constexpr (DIRECT) x[m] = ld_stream<R>(src + (uint64_t)n * sizeof(cx<R>));
+                    else x[m] = decode_sample<R>(src + (uint64_t)n * a.bps, a.kind, a.be != 0);
+                }
+            };
+            cx<R> nxt[TE];
+            load_rows(line_of(0), nxt, std::integral_constant<int, 0>{});
+            __syncthreads();  // table visible
+            for (uint32_t i = 0; i < my_lines; ++i) {
+                const uint32_t slot = i % a.ring, round = i / a.ring;
+                cx<R> v[TE];
+#pragma unroll
+                for (int m = 0; m < TE; ++m) v[m] = nxt[m];
+                if (i + 1 < my_lines) {  // the next line's rows stay in flight behind this FFT
+                    if (half && follows(i + 1)) {
+#pragma unroll
+                        for (int m = 0; m < NEWH; ++m) nxt[m] = nxt[m + NEWH];
+                        load_rows(line_of(i + 1), nxt, std::integral_constant<int, NEWH>{});
+                    } else {
+                        load_rows(line_of(i + 1), nxt, std::integral_constant<int, 0>{});
+                    }
+                }
+                if (win) {
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) {
+                        const R w = win[(uint32_t)(t0 + m * PA::T) * N2 + c0 + q0];
+                        v[m].x *= w;
+                        v[m].y *= w;
+                    }
+                }
+#ifndef SPEC_ABL_TEAM_NOFFT
+                dft8(v);
+#endif
+                xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
+                __syncthreads();
+                xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here
+                __syncthreads();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                pass1<R, L1, WG>(v, t1, tab);
+#endif
+                xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
+                __syncthreads();
+                xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
+                finish(v);
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                if (!team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
+#else
+                __syncthreads();
+#endif
+                cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
+#pragma unroll
+                for (int m = 0; m < TE; ++m) st_slot<R>(dst + t1 + m * PA::T, v[m]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     } else {
         // ================= row side: tile of C rows k1, N2-point transforms over n2, epilogue ===============
+#ifdef SPEC_ABL_TEAM_NOB
+        return;
+#endif
         const uint32_t r0 = (member - NT) * PB::C;
         const int q0 = tid % PB::C, t0 = tid / PB::C;  // rows k1 fastest: the slot reads and the final stores
         cx<R> *tab = lds + (size_t)PB::C * PB::SL;
-        for (int e = tid; e < N2; e += TEAM_WG) tab[e] = static_cast<const cx<R> *>(a.tw2)[e];
+        for (int e = tid; e < N2; e += WG) tab[e] = static_cast<const cx<R> *>(a.tw2)[e];
         __syncthreads();
         cx<R> *line_lds = lds + (size_t)q0 * PB::SL;
-        for (uint32_t i = 0; i < my_lines; ++i) {
-            const uint32_t line = line_first + i, slot = i % a.ring, round = i / a.ring;
-            if (!team_wait(ring + 32 * slot, NT * (round + 1), sync, &s_flag)) return;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                slots + (uint64_t)slot * N, 0, (uint32_t)(N * sizeof(cx<R>)), 0x00020000);
-            cx<R> v[TE];
-#pragma unroll
-            for (int m = 0; m < TE; ++m)  // [n2][k1]
-                v[m] = ld_slot<R>(rs, (int)(((uint32_t)(t0 + m * PB::T) * N1 + r0 + q0) * sizeof(cx<R>)), 0);
-            dft8(v);
-            xstore0<R>(v, t0, line_lds);
+        // the rest of one line behind its first pass and exchange
+        auto rest_of_line = [&](cx<R> (&v)[TE], uint32_t line) {
+            xload<R, L2, WG>(v, t0, line_lds);
             __syncthreads();
-            // every thread has consumed its slot reads: hand the slot back before the rest of the transform
-            if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            xload<R, L2>(v, t0, line_lds);
-            __syncthreads();
-            pass1<R, L2>(v, t0, tab);
+#ifndef SPEC_ABL_TEAM_NOFFT
+            pass1<R, L2, WG>(v, t0, tab);
+#endif
             xstore1<R>(v, t0, line_lds);
             __syncthreads();
-            xload<R, L2>(v, t0, line_lds);
-            pass2<R, L2>(v, t0, tab);
+            xload<R, L2, WG>(v, t0, line_lds);
+#ifndef SPEC_ABL_TEAM_NOFFT
+            pass2<R, L2, WG>(v, t0, tab);
+#endif
             const uint64_t base = (uint64_t)line * N;
+            auto emit = [&](auto fmt_tag) {  // one format per call: the branch on the format is outside the bins
+                constexpr int FMT = decltype(fmt_tag)::value;
 #pragma unroll
-            for (int m = 0; m < TE; ++m) {
-                const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + m * PB::T);
-                store_bin<R>(a.out, base + ((k + N / 2) & (N - 1)), v[m], a.out_fmt);  // SS:78
-                if constexpr (sizeof(R) == 8) __builtin_amdgcn_sched_barrier(0);
+                for (int m = 0; m < TE; ++m) {
+                    const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + m * PB::T);
+                    emit_bin<R, FMT>(a.out, base + ((k + N / 2) & (N - 1)), v[m], s_dbt);  // SS:78
+                    if constexpr (sizeof(R) == 8) __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            asm volatile("" ::: "memory");
+            switch (a.out_fmt) {
+            case OUT_DB20_F32: emit(std::integral_constant<int, OUT_DB20_F32>{}); break;
+            case OUT_POW_F32: emit(std::integral_constant<int, OUT_POW_F32>{}); break;
+            case OUT_DB20_F64: emit(std::integral_constant<int, OUT_DB20_F64>{}); break;
+            default: emit(std::integral_constant<int, OUT_POW_F64>{}); break;
             }
+            asm volatile("" ::: "memory");
             __syncthreads();  // the line buffers are rewritten by the next line's first exchange
+        };
+        auto ready = [&](uint32_t j, uint32_t w) { return j < my_lines && (int32_t)(w - NT * (j / a.ring + 1)) >= 0; };
+        if constexpr (LD::PIPE) {
+            // ---- pipelined form (fp64) --------------------------------------------------------------------------------
+            // Per line: [tile of line i + 1 into the strips, if the column side has it (poll taken one line earlier)]
+            // [poll for line i + 2] [the 8 output stores of line i].  The tile is read at the top of the next
+            // iteration behind vm_wait<8>: the loads and the poll are older than the stores, the stores stay in flight.
+            auto issue = [&](uint32_t i) {
+                const cx<R> *src = slots + (uint64_t)(i % a.ring) * N + r0 + q0;
+#pragma unroll
+                for (int m = 0; m < TE; ++m) glds16<1>(src + (uint64_t)(t0 + m * PB::T) * N1, land_addr + 1024u * m);  // [n2][k1]
+            };
+            auto issue_poll = [&](uint32_t j) {  // doneA of line j's slot (lane 0)
+                if (tid == 0 && j < my_lines) glds4_sc1(ring + 32 * (j % a.ring), pland_addr);
+            };
+#ifndef SPEC_ABL_TEAM_NOWAIT
+            if (!team_wait(ring, NT, sync, &s_flag)) return;
+#endif
+            issue(0);
+            issue_poll(1);
+            vm_wait<0>();  // the first tile: nothing to overlap with yet
+            for (uint32_t i = 0; i < my_lines; ++i) {
+                const uint32_t slot = i % a.ring;
+                vm_wait<TEAM_NST>();  // tile i and the poll have landed; the stores of line i - 1 fly on
+                cx<R> v[TE];
+#pragma unroll
+                for (int m = 0; m < TE; ++m) v[m] = land[64 * m + lane];
+#ifndef SPEC_ABL_TEAM_NOFFT
+                dft8(v);
+#endif
+                xstore0<R>(v, t0, line_lds);
+                if (tid == 0) s_next = ready(i + 1, pland[0]);
+                __syncthreads();
+                // every thread has consumed its slot reads: hand the slot back before the rest of the transform
+                if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SPEC_ABL_TEAM_NOWAIT
+                const bool ahead = i + 1 < my_lines;
+#else
+                const bool ahead = s_next != 0;
+#endif
+                if (ahead) issue(i + 1);
+                issue_poll(i + 2);
+                rest_of_line(v, line_of(i));
+                if (!ahead && i + 1 < my_lines) {  // the column side is not ahead: wait for it here
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                    if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
+#endif
+                    issue(i + 1);
+                    vm_wait<0>();  // nothing younger to leave in flight on this path
+                }
+            }
+        } else {
+            // ---- plain form (fp32): the next tile requested as soon as the column side has it, loads the compiler knows
+            auto load_tile = [&](uint32_t i, cx<R> (&x)[TE]) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    slots + (uint64_t)(i % a.ring) * N, 0, (uint32_t)(N * sizeof(cx<R>)), 0x00020000);
+#pragma unroll
+                for (int m = 0; m < TE; ++m)  // [n2][k1]
+                    x[m] = ld_slot<R>(rs, (int)(((uint32_t)(t0 + m * PB::T) * N1 + r0 + q0) * sizeof(cx<R>)));
+            };
+            cx<R> nxt[TE];
+#ifndef SPEC_ABL_TEAM_NOWAIT
+            if (!team_wait(ring, NT, sync, &s_flag)) return;
+#endif
+            load_tile(0, nxt);
+            for (uint32_t i = 0; i < my_lines; ++i) {
+                const uint32_t slot = i % a.ring;
+                cx<R> v[TE];
+#pragma unroll
+                for (int m = 0; m < TE; ++m) v[m] = nxt[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
+                dft8(v);
+#endif
+                xstore0<R>(v, t0, line_lds);
+                if (tid == 0) s_next = ready(i + 1, ld_sc1(ring + 32 * ((i + 1) % a.ring)));
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ahead = s_next != 0;
+                if (ahead) load_tile(i + 1, nxt);
+                rest_of_line(v, line_of(i));
+                if (!ahead && i + 1 < my_lines) {
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                    if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
+#endif
+                    load_tile(i + 1, nxt);
+                }
+            }
         }
     }
 }
 
-template <typename R, int L1, int L2> constexpr size_t team_lds_bytes() {
-    constexpr size_t a = ((size_t)TP<L1>::C * TP<L1>::SL + TP<L1>::M) * sizeof(cx<R>);
-    constexpr size_t b = ((size_t)TP<L2>::C * TP<L2>::SL + TP<L2>::M) * sizeof(cx<R>);
-    return a > b ? a : b;
-}
+template <typename R, int L1, int L2, int WG> constexpr size_t team_lds_bytes() { return TeamLds<R, L1, L2, WG>::BYTES; }
 
-template <typename R, int L1, int L2>
-hipError_t launch_team(const TeamArgs &a, int n_cu, uint32_t *teams_max, hipStream_t s, bool query_only) {
-    constexpr size_t lds = team_lds_bytes<R, L1, L2>();
+template <typename R, int L1, int L2, int WG>
+hipError_t launch_team_wg(const TeamArgs &a, int n_cu, uint32_t *teams_max, hipStream_t s, bool query_only) {
+    constexpr size_t lds = team_lds_bytes<R, L1, L2, WG>();
     const bool direct = !a.be && a.kind == (sizeof(R) == 8 ? K_CF64 : K_CF32);
-    auto fn = direct ? &large_team_kernel<R, L1, L2, true> : &large_team_kernel<R, L1, L2, false>;
+    const bool half = (uint64_t)a.hop * 2 == ((uint64_t)1 << (L1 + L2));
+    auto fn = direct ? (half ? &large_team_kernel<R, L1, L2, true, true, WG> : &large_team_kernel<R, L1, L2, true, false, WG>)
+                     : (half ? &large_team_kernel<R, L1, L2, false, true, WG> : &large_team_kernel<R, L1, L2, false, false, WG>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int per_cu = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TEAM_WG, lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WG, lds);
     if (e != hipSuccess) return e;
-    if (per_cu > 2) per_cu = 2;  // one column and one row workgroup per CU; more teams would not fit the L2
+    // 512 threads of intermediate per CU and no more: two lines in flight per XCD is what its L2 holds
+    constexpr int WANT = 512 / WG;
+    if (per_cu > WANT) per_cu = WANT;
     if (per_cu < 1) return hipErrorLaunchOutOfResources;
     const uint32_t grid = (uint32_t)per_cu * (uint32_t)n_cu;
-    constexpr uint32_t TEAM = 2 * ((1u << (L1 + L2)) / (TEAM_WG * TE));
+    constexpr uint32_t TEAM = 2 * ((1u << (L1 + L2)) / (WG * TE));
     *teams_max = grid / TEAM;
     if (query_only) return hipSuccess;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(TEAM_WG), lds, s, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(WG), lds, s, a);
     return hipGetLastError();
+}
+template <typename R, int L1, int L2>
+hipError_t launch_team(const TeamArgs &a, int wg, int n_cu, uint32_t *teams_max, hipStream_t s, bool query_only) {
+    (void)wg;  // 512-thread workgroups (16-wide tiles); 256 measured slower in every configuration
+    return launch_team_wg<R, L1, L2, 512>(a, n_cu, teams_max, s, query_only);
 }
 
 }  // namespace
@@ -373,22 +704,24 @@ uint32_t large_team_abort_word() { return TS_ABORT; }
 // complete.  `scratch` holds teams_max * ring * N complex values (query with query_only first).
 hipError_t launch_spectro_team(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2, void *scratch,
                                uint32_t ring, uint32_t *sync, int n_cu, uint32_t *teams_max, bool query_only,
-                               hipStream_t s) {
+                               hipStream_t s, int wg, uint32_t block) {
+    if (wg != 256 && wg != 512) return hipErrorInvalidValue;
     TeamArgs a{};
     a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.bps = w.bps; a.kind = w.kind; a.be = w.be;
     a.tw1 = tw1; a.tw2 = tw2; a.twn = w.tw; a.win = w.win; a.scratch = scratch; a.out = w.out; a.out_fmt = w.out_fmt;
     a.ring = ring < 1 ? 1 : (ring > (uint32_t)TEAM_RING_MAX ? (uint32_t)TEAM_RING_MAX : ring);
+    a.block = block;
     a.sync = sync;
     if (f64) {
         switch (log2n) {
-        case 14: return launch_team<double, 7, 7>(a, n_cu, teams_max, s, query_only);
-        case 15: return launch_team<double, 7, 8>(a, n_cu, teams_max, s, query_only);
-        case 16: return launch_team<double, 8, 8>(a, n_cu, teams_max, s, query_only);
+        case 14: return launch_team<double, 7, 7>(a, wg, n_cu, teams_max, s, query_only);
+        case 15: return launch_team<double, 7, 8>(a, wg, n_cu, teams_max, s, query_only);
+        case 16: return launch_team<double, 8, 8>(a, wg, n_cu, teams_max, s, query_only);
         }
     } else {
         switch (log2n) {
-        case 15: return launch_team<float, 7, 8>(a, n_cu, teams_max, s, query_only);
-        case 16: return launch_team<float, 8, 8>(a, n_cu, teams_max, s, query_only);
+        case 15: return launch_team<float, 7, 8>(a, wg, n_cu, teams_max, s, query_only);
+        case 16: return launch_team<float, 8, 8>(a, wg, n_cu, teams_max, s, query_only);
         }
     }
     return hipErrorInvalidValue;

@@ -26,4 +26,21 @@ hipError_t launch_v3d_spectro(const WfArgs &w, int log2n, uint32_t run, hipStrea
     }
 }
 
+// fp64 Welch partial sums (spec_v3d.h MODE 1): w.partial receives double slabs [n_psd][wgs * LPW][N]
+int v3d_lpw(int log2n) { return log2n == 13 ? 1 : v2_lpw(log2n); }
+hipError_t launch_v3d_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t wgs_per_unit, hipStream_t s) {
+    V2Args a{};
+    a.iq = w.iq; a.unit_stride = w.psd_stride_bytes; a.n_units = w.n_psd; a.n_lines = w.n_seg; a.hop = w.hop;
+    a.run = run; a.wgs_per_unit = wgs_per_unit; a.tw = w.tw; a.win = w.win; a.out = w.partial; a.out_fmt = 0; a.be = w.be;
+    switch (log2n) {
+    case 8: return v3d_launch_welch_kind<8>(a, w.kind, s);
+    case 9: return v3d_launch_welch_kind<9>(a, w.kind, s);
+    case 10: return v3d_launch_welch_kind<10>(a, w.kind, s);
+    case 11: return v3d_launch_welch_kind<11>(a, w.kind, s);
+    case 12: return v3d_launch_welch_kind<12>(a, w.kind, s);
+    case 13: return v3d_launch_welch_kind<113>(a, w.kind, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 }  // namespace specgpu

@@ -23,15 +23,16 @@ hipError_t launch_fill(void *out, uint64_t n, double value, int is_f64, hipStrea
 // owns 32 bins; its 8 lanes per bin each sum every 8th slab and are combined in lane order, so
 // the result does not depend on scheduling (bitwise reproducible, no atomics) while a single
 // 256-slab PSD is no longer one long dependent chain per bin.
-__global__ __launch_bounds__(256) void welch_finalize_kernel(const float *__restrict__ partial, uint32_t n_slabs,
+template <typename TS, typename TO>
+__global__ __launch_bounds__(256) void welch_finalize_kernel(const TS *__restrict__ partial, uint32_t n_slabs,
                                                              uint32_t nfft, double norm, int db,
-                                                             float *__restrict__ psd_out) {
+                                                             TO *__restrict__ psd_out) {
     __shared__ double part[8][32];
     const uint32_t psd = blockIdx.y, b = threadIdx.x & 31, lane = threadIdx.x >> 5;
     const uint32_t k = blockIdx.x * 32 + b;
     double acc = 0;
     if (k < nfft) {
-        const float *p = partial + (uint64_t)psd * n_slabs * nfft + k;
+        const TS *p = partial + (uint64_t)psd * n_slabs * nfft + k;
 #pragma unroll 4
         for (uint32_t sl = lane; sl < n_slabs; sl += 8) acc += (double)p[(uint64_t)sl * nfft];
     }
@@ -43,17 +44,28 @@ __global__ __launch_bounds__(256) void welch_finalize_kernel(const float *__rest
         for (int l = 1; l < 8; ++l) t += part[l][b];
         const double v = t * norm;
         const uint32_t ks = (k + nfft / 2) & (nfft - 1);
-        psd_out[(uint64_t)psd * nfft + ks] = db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+        psd_out[(uint64_t)psd * nfft + ks] = db ? (TO)(10.0 * log10(v + 1e-20)) : (TO)v;
     }
 }
 
-hipError_t launch_welch_finalize(const float *partial, uint32_t n_psd, uint32_t n_slabs, uint32_t nfft,
-                                 double norm, int db, float *psd_out, hipStream_t s) {
+template <typename TS, typename TO>
+static void finalize_launch(const void *partial, uint32_t n_psd, uint32_t n_slabs, uint32_t nfft, double norm, int db,
+                            void *psd_out, hipStream_t s) {
     for (uint32_t p0 = 0; p0 < n_psd; p0 += 65535) {  // grid.y limit
         const uint32_t np = n_psd - p0 < 65535 ? n_psd - p0 : 65535;
-        hipLaunchKernelGGL(welch_finalize_kernel, dim3((nfft + 31) / 32, np), dim3(256), 0, s,
-                           partial + (uint64_t)p0 * n_slabs * nfft, n_slabs, nfft, norm, db,
-                           psd_out + (uint64_t)p0 * nfft);
+        hipLaunchKernelGGL((welch_finalize_kernel<TS, TO>), dim3((nfft + 31) / 32, np), dim3(256), 0, s,
+                           static_cast<const TS *>(partial) + (uint64_t)p0 * n_slabs * nfft, n_slabs, nfft, norm, db,
+                           static_cast<TO *>(psd_out) + (uint64_t)p0 * nfft);
+    }
+}
+hipError_t launch_welch_finalize(const void *partial, int slabs_f64, uint32_t n_psd, uint32_t n_slabs, uint32_t nfft,
+                                 double norm, int db, void *psd_out, int out_f64, hipStream_t s) {
+    if (slabs_f64) {
+        if (out_f64) finalize_launch<double, double>(partial, n_psd, n_slabs, nfft, norm, db, psd_out, s);
+        else finalize_launch<double, float>(partial, n_psd, n_slabs, nfft, norm, db, psd_out, s);
+    } else {
+        if (out_f64) finalize_launch<float, double>(partial, n_psd, n_slabs, nfft, norm, db, psd_out, s);
+        else finalize_launch<float, float>(partial, n_psd, n_slabs, nfft, norm, db, psd_out, s);
     }
     return hipGetLastError();
 }

@@ -12,8 +12,11 @@ namespace specgpu {
 
 namespace {
 
-// spectrogram lines (MC:980-999 around SS:33-85), fp64 arithmetic; OUT64: doubles out, else floats
-template <int L, int KIND, int SH, bool HAS_WIN, bool BE>
+// MODE 0: spectrogram lines (MC:980-999 around SS:33-85), fp64 arithmetic; doubles or floats out.
+// MODE 1: Welch partial sums in fp64 (the dialog's calculatePsdWelch call, ADC:308-312, and cf64 / big-endian /
+// fp64-output PSDs): every sub-line adds |X|^2 of its run of segments in registers and leaves ONE double slab;
+// welch_finalize_kernel sums the slabs in a fixed order.  No power line ever reaches HBM.
+template <int L, int KIND, int SH, bool HAS_WIN, bool BE, int MODE = 0>
 __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
     using PL = Plan2<L>;
     using RW = Raw2<KIND>;
@@ -33,13 +36,14 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
     const double *win = static_cast<const double *>(a.win);
     if constexpr (PL::NPASS > 2) __syncthreads();
 
-    const uint32_t wg = blockIdx.x;
+    const uint32_t unit = blockIdx.x / a.wgs_per_unit, wg = blockIdx.x % a.wgs_per_unit;
     const uint32_t line0 = wg * (uint32_t)PL::LPW * a.run;
     uint32_t lines_wg = a.n_lines - line0;
     if (lines_wg > (uint32_t)PL::LPW * a.run) lines_wg = PL::LPW * a.run;
     const uint32_t line_bytes = a.hop * BPS;
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(a.iq) + (uint64_t)line0 * line_bytes, 0, (lines_wg - 1) * line_bytes + (uint32_t)N * BPS, 0x00020000);
+        const_cast<uint8_t *>(a.iq) + (uint64_t)unit * a.unit_stride + (uint64_t)line0 * line_bytes, 0,
+        (lines_wg - 1) * line_bytes + (uint32_t)N * BPS, 0x00020000);
     const int voff = (int)(q * a.run * line_bytes) + t * BPS;
     constexpr int AUX = 2, ST_AUX = 2;
     constexpr int NEW = SH > 0 ? SH : E;
@@ -64,6 +68,11 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
     const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
     const uint32_t iters = PL::WAVE_LOCAL ? a.run : my_lines;
     constexpr double scale = (double)RW::SCALE;
+    double acc[MODE == 1 ? E : 1];
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) acc[m] = 0.0;
+    }
 
     for (uint32_t line = 0; line < iters; ++line) {
         v2d v[E];
@@ -92,6 +101,13 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
 
         v2_fft<L>(v, t, lds, tab, twl);
 
+        if constexpr (MODE == 1) {
+            if (line < my_lines) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) acc[m] += pk_norm(v[m]);
+            }
+            continue;
+        }
         // out[(k + N/2) mod N] = 20 log10(|X_k| + 1e-10)  (SS:78-81), or |X_k|^2
         const int out_off = (int)(line * (uint32_t)N * esz);
 #pragma unroll
@@ -107,19 +123,43 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
             __builtin_amdgcn_sched_barrier(0);  // one bin's sqrt / log series at a time
         }
     }
+    if constexpr (MODE == 1) {  // one fp64 slab per sub-line (zeros for idle ones), unshifted bins
+        double *slab = static_cast<double *>(a.out) + ((uint64_t)blockIdx.x * PL::LPW + q) * N;
+#pragma unroll
+        for (int m = 0; m < E; ++m) slab[t + m * T] = acc[m] * (scale * scale);
+    }
 }
 
-template <int L, int KIND, int SH, bool HAS_WIN, bool BE = false>
+template <int L, int KIND, int SH, bool HAS_WIN, bool BE = false, int MODE = 0>
 hipError_t v3d_launch1(const V2Args &a, hipStream_t s) {
     using PL = Plan2<L>;
     constexpr size_t lds = p2_lds_bytes<L, 16>();
-    auto kern = v3d_kernel<L, KIND, SH, HAS_WIN, BE>;
+    auto kern = v3d_kernel<L, KIND, SH, HAS_WIN, BE, MODE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(a.wgs_per_unit), dim3(PL::WG), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.wgs_per_unit * (a.n_units ? a.n_units : 1)), dim3(PL::WG), lds, s, a);
     return hipGetLastError();
+}
+
+// Welch partial sums: always through the window table (rectangular = ones: one variant per format), the overlap
+// re-read from L2 (any hop); big-endian files by the swapping variant
+template <int L, int KIND> hipError_t v3d_launch_welch(const V2Args &a, hipStream_t s) {
+    if constexpr (KIND == K_CF32 || KIND == K_CI16 || KIND == K_CF64) {
+        if (a.be) return v3d_launch1<L, KIND, 0, true, true, 1>(a, s);
+    }
+    return v3d_launch1<L, KIND, 0, true, false, 1>(a, s);
+}
+template <int L> hipError_t v3d_launch_welch_kind(const V2Args &a, int kind, hipStream_t s) {
+    switch (kind) {
+    case K_CF64: return v3d_launch_welch<L, K_CF64>(a, s);
+    case K_CF32: return v3d_launch_welch<L, K_CF32>(a, s);
+    case K_CI16: return v3d_launch_welch<L, K_CI16>(a, s);
+    case K_CU8: return v3d_launch_welch<L, K_CU8>(a, s);
+    case K_CI8: return v3d_launch_welch<L, K_CI8>(a, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // register-reuse variant for 50 % overlap; every other hop and big-endian files re-read the overlap from L2

@@ -62,6 +62,60 @@ class SigMfRecording:
         """The single call of MC:988-993."""
         return svc.compute_magnitudes(self.buffer, byte_offset, fft_size, self.datatype, self.big_endian)
 
+    # -- the same through the library's own file reader (include/specgpu.h, spec_open_recording) --------
+    def open_native(self, svc: SpectralService) -> "NativeRecording":
+        """The data file handed to the library by PATH (``spec_open_recording``): it preads the slices it
+        needs into a pinned ring, 64-bit offsets, no mapping -- what a Java host uses instead of the
+        <= 2 GiB ``MappedByteBuffer`` of ``SigMfHelper.java:78-84``."""
+        return NativeRecording(svc, self)
+
+
+class NativeRecording:
+    """``spec_recording`` handle of one data file; close it (or use ``with``) before the service."""
+
+    def __init__(self, svc: SpectralService, rec: SigMfRecording):
+        import ctypes as C
+        self._svc, self.rec = svc, rec
+        self._h = C.c_void_p()
+        svc._check(svc._lib.spec_open_recording(svc._ctx, os.fsencode(rec.data_path), int(rec.header_bytes),
+                                                C.byref(self._h)))
+
+    @property
+    def n_bytes(self) -> int:
+        return int(self._svc._lib.spec_recording_bytes(self._h))
+
+    def waterfall(self, current_sample_offset: int, fft_size: int, canvas_w: int, hop: Optional[int] = None,
+                  window: int = L.WIN_RECT, out_fmt: int = L.OUT_DB20_F32, eof_fill: float = -150.0) -> np.ndarray:
+        """MC:980-999 on the file itself: line t starts at sample ``offset + t * hop``."""
+        hop = int(fft_size if hop is None else hop)
+        out = np.empty((int(canvas_w), int(fft_size)), dtype=np.float64 if out_fmt >= L.OUT_DB20_F64 else np.float32)
+        svc = self._svc
+        svc._check(svc._lib.spec_waterfall_recording(
+            svc._ctx, self._h, int(current_sample_offset) * self.rec.bytes_per_sample,
+            svc._lib.spec_dtype_from_sigmf(self.rec.datatype.encode()), int(fft_size), hop, int(canvas_w), window,
+            out_fmt, float(eof_fill), out.ctypes.data, 0))
+        return out
+
+    def compute_magnitudes(self, byte_offset: int, fft_size: int) -> np.ndarray:
+        """SS:33-85 with a 64-bit ``startByte``."""
+        out = np.empty(max(int(fft_size), 0), dtype=np.float64)
+        svc = self._svc
+        svc._check(svc._lib.spec_compute_magnitudes_recording(
+            svc._ctx, self._h, int(byte_offset), int(fft_size) & 0xFFFFFFFF, self.rec.datatype.encode(),
+            int(self.rec.big_endian), out.ctypes.data))
+        return out
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            self._svc._lib.spec_close_recording(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
 
 def load(meta_path: str) -> SigMfRecording:
     """``SigMfHelper.load`` (SigMfHelper.java:43-94) without the 2 GiB cap."""

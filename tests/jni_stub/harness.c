@@ -33,6 +33,11 @@ void SS(nativeWaterfallRender)(JNIEnv *, jclass, jlong, jobject, jlong, jint, ji
 void SS(nativeWelchPlanar)(JNIEnv *, jclass, jlong, jdoubleArray, jdoubleArray, jint, jint, jint, jint, jdouble,
                            jboolean, jdoubleArray, jdoubleArray);
 jint SS(nativeDtype)(JNIEnv *, jclass, jstring);
+jlong SS(nativeOpenRecording)(JNIEnv *, jclass, jlong, jstring, jlong);
+jlong SS(nativeRecordingBytes)(JNIEnv *, jclass, jlong);
+void SS(nativeCloseRecording)(JNIEnv *, jclass, jlong);
+void SS(nativeWaterfallRecording)(JNIEnv *, jclass, jlong, jlong, jlong, jint, jint, jint, jlong, jint, jdouble, jfloatArray);
+void SS(nativeComputeMagnitudesRecording)(JNIEnv *, jclass, jlong, jlong, jlong, jint, jstring, jboolean, jdoubleArray);
 void SS(nativeTrace)(JNIEnv *, jclass, jlong, jint, jdoubleArray, jdoubleArray, jdouble, jdouble, jdouble, jdoubleArray);
 jlong EDC(nativeCreate)(JNIEnv *, jclass, jint, jint);
 void EDC(nativeDestroy)(JNIEnv *, jclass, jlong);
@@ -181,6 +186,36 @@ int main(void) {
     fake_obj a_tile_short = mk_array(tile, LINES * NFFT - 1, 4);
     SS(nativeWaterfall)(env, NULL, h, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile_short);
     expect_throw("java/lang/IllegalArgumentException", "shorter than nLines", "short tile");
+
+    /* the same recording as a FILE with a 100-byte header, opened by path (SigMfHelper.java:69-94 replaced) */
+    {
+        char path[] = "/tmp/specgpu_jni_XXXXXX";
+        const int fd = mkstemp(path);
+        CHECK(fd >= 0, "mkstemp");
+        FILE *f = fdopen(fd, "wb");
+        char hdr[100];
+        memset(hdr, 0x5A, sizeof hdr);
+        CHECK(f && fwrite(hdr, 1, sizeof hdr, f) == sizeof hdr && fwrite(rec, 4, SAMPLES, f) == SAMPLES, "write");
+        if (f) fclose(f);
+        fake_obj jpath = mk_string(path);
+        const jlong r = SS(nativeOpenRecording)(env, NULL, h, &jpath, 100);
+        expect_clean("openRecording");
+        CHECK(SS(nativeRecordingBytes)(env, NULL, r) == SAMPLES * 4, "recording length");
+        memset(tile, 0, (size_t)LINES * NFFT * 4);
+        SS(nativeWaterfallRecording)(env, NULL, h, r, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile);
+        expect_clean("computeWaterfall(recording)");
+        CHECK(memcmp(tile, tile_ref, (size_t)LINES * NFFT * 4) == 0, "computeWaterfall(recording) differs from the mapped-buffer result");
+        SS(nativeComputeMagnitudesRecording)(env, NULL, h, r, 400, NFFT, &dts, 0, &a_line);
+        expect_clean("computeMagnitudes(recording)");
+        CHECK(memcmp(line, line_ref, sizeof line) == 0, "computeMagnitudes(recording) differs");
+        SS(nativeComputeMagnitudesRecording)(env, NULL, h, r, (jlong)SAMPLES * 4 - 8, NFFT, &dts, 0, &a_line);
+        expect_throw("java/lang/IndexOutOfBoundsException", "IndexOutOfBounds", "recording slice past the end");
+        SS(nativeCloseRecording)(env, NULL, r);
+        fake_obj nopath = mk_string("/nonexistent/specgpu.sigmf-data");
+        CHECK(SS(nativeOpenRecording)(env, NULL, h, &nopath, 0) == 0, "missing file");
+        expect_throw("java/lang/IllegalArgumentException", "cannot open", "missing data file");
+        remove(path);
+    }
 
     /* Welch over raw bytes + the dialog's planar call (ADC:303-313), including a non power-of-two length */
     double freq[NFFT], freq_ref[NFFT];

@@ -97,3 +97,74 @@ def test_team_kernel_repeated_launches_are_identical(team, oracle):
     host = iq.cpu().numpy()
     ref = np.stack([oracle.waterfall(host, l * hop * 8, datatype, nfft, hop, 1)[0] for l in sample])
     check_fp32(first[sample].cpu().numpy(), ref, nfft)
+
+
+# ---- BASELINE configs[4] at its real per-GPU shape: 65536-pt cf64 -> f64, hop 32768, 2^30 samples ---------
+@pytest.mark.parametrize("mode", [1, 0])
+def test_cfg5_full_size_properties(svc, oracle, mode):
+    """16 GiB in, 16 GiB out, 32 767 lines (+ 3 past the end): default dispatch (team kernel with the guarded
+    fall-back behind it) and the two-launch path, which at this size crosses its 1024-line chunk loop."""
+    import torch
+    datatype, nfft, hop, S = "cf64_le", 65536, 32768, 1 << 30
+    bps = 16
+    n_lines = (S - nfft) // hop + 1
+    svc.set_option("large_team", mode)
+    try:
+        iq = svc.synth_iq(datatype, 0x5EC7A11A, 0, S)
+        out = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + 3, hop=hop, out_fmt=sa.OUT_DB20_F64)
+        torch.cuda.synchronize()
+        assert out.shape == (n_lines + 3, nfft) and out.dtype == torch.float64
+        assert bool((out[n_lines:] == -150.0).all())                       # EOF lines (MC:994-998)
+        assert bool(torch.isfinite(out).all())
+        peak = out[:n_lines].argmax(dim=1)                                  # the 0.123 cycles/sample tone
+        k = int(round(0.123 * nfft)) + nfft // 2
+        assert bool(((peak - k).abs() <= 1).all())
+        rng = np.random.default_rng(2)
+        picks = [0, 1, 1023, 1024, 1025, n_lines - 1] + [int(x) for x in rng.integers(0, n_lines, 4)]
+        for ln in picks:                                                    # chunk seams of the two-launch path included
+            raw = iq[ln * hop * bps:(ln * hop + nfft) * bps].cpu().numpy()
+            ref = oracle.waterfall(raw, 0, datatype, nfft, hop, 1)
+            check_fp64(out[ln].cpu().numpy()[None, :], ref)
+        # Parseval, every line: sum |X|^2 = N sum |x|^2 (fp64: 1e-12)
+        lines = torch.arange(0, n_lines, 997, device=out.device)
+        mag2 = torch.pow(10.0, out[lines] / 10.0).sum(dim=1)
+        x = iq.view(torch.float64).view(-1, 2)
+        for j, ln in enumerate(lines.tolist()):
+            e = float((x[ln * hop:ln * hop + nfft] ** 2).sum()) * nfft
+            assert float(mag2[j]) == pytest.approx(e, rel=1e-9)             # 20 log10(|X| + 1e-10): tiny bins bias
+        del out, iq
+        torch.cuda.empty_cache()
+    finally:
+        svc.set_option("large_team", 1)
+
+
+# ---- BASELINE configs[3] at its real shape: Welch 16384-pt, Hann, hop 4096, 256 segments, batched ------------
+def test_cfg4_full_size_properties(svc, oracle):
+    import torch
+    datatype, nfft, hop, n_seg, n_psd, fs = "cf32_le", 16384, 4096, 256, 64, 2.0e6
+    per = (n_seg - 1) * hop + nfft                                          # 1 060 864 samples per PSD
+    iq = svc.synth_iq(datatype, 0x5EC7A11A, 0, per * n_psd)
+    f, p = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=sa.WIN_HANN, n_psd=n_psd,
+                         psd_stride_bytes=per * 8)
+    torch.cuda.synchronize()
+    assert p.shape == (n_psd, nfft) and bool(torch.isfinite(p).all()) and bool((p > 0).all())
+    assert np.allclose(f, (np.arange(nfft) - nfft // 2) * fs / nfft)
+    for b in (0, 31, n_psd - 1):                                            # sampled PSDs against the oracle
+        raw = iq[b * per * 8:(b + 1) * per * 8].cpu().numpy()
+        _, ref = oracle.welch_psd(raw, 0, datatype, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY, fs)
+        assert np.abs(p[b].cpu().numpy() - ref).max() <= 5e-6 * ref.max()
+    # Parseval for EVERY PSD: sum_k P[k] fs sum(w^2) = N mean_seg sum_n |w x|^2
+    w = torch.from_numpy(oracle.np_window(nfft, oracle.WIN_HANN)).to(iq.device)
+    s2 = float((w * w).sum())
+    x = iq.view(torch.float32).view(n_psd, per, 2).double()
+    for b in range(n_psd):
+        seg = x[b].unfold(0, nfft, hop)                                     # [n_seg, 2, nfft] view
+        e = float(((seg * w) ** 2).sum()) / n_seg * nfft
+        assert float(p[b].double().sum()) * fs * s2 == pytest.approx(e, rel=2e-5)
+    # one PSD alone equals the same PSD inside the batch (batching changes the run lengths, not the numbers'
+    # tolerance), and the dB form
+    _, one = svc.welch_psd(iq, 17 * per * 8, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=sa.WIN_HANN)
+    torch.cuda.synchronize()
+    assert float((one[0] - p[17]).abs().max() / p[17].max()) <= 2e-6
+    del iq, p, x
+    torch.cuda.empty_cache()

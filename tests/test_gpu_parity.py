@@ -187,3 +187,42 @@ def test_observed_fp32_error_per_tier(svc, oracle, capsys):
               "max |dB| on bins >= 1e-3 M [tol 2e-3], on bins >= 1e-4 M [tol 4e-3]")
         for r in rows:
             print("  %-8s nfft %5d   %.3g   %.3g dB   %.3g dB" % r)
+
+
+@pytest.mark.parametrize("case", ["fp32", "fp64", "welch", "render"])
+def test_partial_last_workgroup_writes_nothing_past_the_tile(svc, oracle, case):
+    """The wave-local plans run every sub-line of the last workgroup for the full run length and rely on the
+    buffer descriptor's range check to drop the stores of lines that do not exist.  The output is handed over as
+    a view into a larger tensor: the rows behind it must keep their sentinel."""
+    import torch
+    nfft, hop, n_lines, sentinel = 1024, 512, 3 * 7 + 2, 12345.0      # 23 lines, runs of 3: ragged last workgroup
+    datatype = "ci16_le"
+    iq = torch.from_numpy(oracle.synth_iq(datatype, 4, 0, (n_lines - 1) * hop + nfft)).cuda()
+    svc.set_option("lines_per_wg", 3)
+    try:
+        if case in ("fp32", "fp64"):
+            dt = torch.float32 if case == "fp32" else torch.float64
+            big = torch.full((n_lines + 40, nfft), sentinel, dtype=dt, device="cuda")
+            svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out=big[:n_lines],
+                                  out_fmt=sa.OUT_DB20_F32 if case == "fp32" else sa.OUT_DB20_F64)
+            torch.cuda.synchronize()
+            assert bool((big[n_lines:] == sentinel).all()) and not bool((big[:n_lines] == sentinel).any())
+        elif case == "welch":
+            big = torch.full((1 + 8, nfft), sentinel, dtype=torch.float32, device="cuda")
+            svc.welch_psd(iq, 0, datatype, 1e6, nfft=nfft, hop=hop, n_seg=n_lines, out=big[:1])
+            torch.cuda.synchronize()
+            assert bool((big[1:] == sentinel).all()) and not bool((big[:1] == sentinel).any())
+        else:
+            # fused redraw: the image is exactly height x width x 4 bytes; sentinel bytes behind it
+            import ctypes as C
+            from spectral_analyzer_amd import _lib as L
+            height = 300
+            img = torch.full((height * n_lines * 4 + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+            st = svc._lib.spec_waterfall_render(svc._ctx, iq.data_ptr(), 1, iq.numel(), 0, L.DT_CI16_LE, nfft, hop, n_lines,
+                                                L.WIN_RECT, height, 1e6, -120.0, 0.0, L.CMAP_HEATMAP, img.data_ptr(), 1)
+            assert st == L.SPEC_OK
+            torch.cuda.synchronize()
+            assert bool((img[height * n_lines * 4:] == 0xA5).all())
+            assert bool((img[3:height * n_lines * 4:4] == 255).all())          # alpha of every pixel was written
+    finally:
+        svc.set_option("lines_per_wg", 0)

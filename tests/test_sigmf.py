@@ -62,3 +62,62 @@ def test_sigmf_file_end_to_end(tmp_path, oracle, svc, datatype):
     check_fp32(got[:valid], ref[:valid], nfft)
     one = rec.compute_magnitudes(svc, off * rec.bytes_per_sample, nfft)
     check_fp64(one[None, :], oracle.compute_magnitudes(raw, off * rec.bytes_per_sample, nfft, datatype, cf64_decode=True)[None, :])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dataset", [None, "big capture.raw"])
+def test_recording_larger_than_2_gib(tmp_path, oracle, svc, dataset):
+    """SigMfHelper.java:78-84 maps at most 2 GiB - 1 bytes and MainController.java:985 casts the byte offset to
+    int.  Here: a sparse 5 GiB data file (header 1000 bytes; three written windows, the rest holes), read by
+    the library itself through spec_open_recording -- lines at byte offsets beyond 2^31 and 2^32 match the
+    oracle, holes are silence (-200 dB, SS:81), lines that run past the end are -150.0 (MC:994-998)."""
+    from test_gpu_parity import check_fp32, check_fp64
+    datatype, nfft, header = "ci16_le", 4096, 1000
+    bps = 4
+    total_samples = (5 << 30) // bps + 123                      # not a whole number of lines
+    name = dataset or "big.sigmf-data"
+    data_path = tmp_path / name
+    windows = {}                                                # first sample -> raw bytes
+    with open(data_path, "wb") as f:
+        f.truncate(header + total_samples * bps)
+        for first in (0, (1 << 31) // bps + 77, (1 << 32) // bps + 4096 * 3 + 5, total_samples - 3 * nfft - 10):
+            n = 3 * nfft + 10
+            raw = oracle.synth_iq(datatype, 100 + len(windows), first, n)
+            f.seek(header + first * bps)
+            f.write(raw.tobytes())
+            windows[first] = raw
+    meta = {"global": {"core:datatype": datatype, "core:sample_rate": 1e6}, "captures": [{"core:header_bytes": header}]}
+    if dataset:
+        meta["global"]["core:dataset"] = dataset
+    mp = tmp_path / "big.sigmf-meta"
+    mp.write_text(json.dumps(meta))
+    rec = sigmf.load(str(mp))
+    assert rec.total_samples == total_samples and rec.header_bytes == header
+    with rec.open_native(svc) as nat:
+        assert nat.n_bytes == total_samples * bps > (1 << 32)
+        for first, raw in windows.items():
+            got = nat.waterfall(first, nfft, 3)                  # hop = fftSize, as MC:984
+            ref = oracle.waterfall(raw, 0, datatype, nfft, nfft, 3)
+            check_fp32(got, ref, nfft)
+            one = nat.compute_magnitudes(first * bps, nfft)      # a startByte no int can hold (MC:985)
+            check_fp64(one[None, :], oracle.compute_magnitudes(raw, 0, nfft, datatype)[None, :])
+        hole = nat.waterfall((3 << 30) // bps, nfft, 2)
+        assert np.all(hole == -200.0)                            # zeros -> 20 log10(1e-10)
+        tail = nat.waterfall(total_samples - 3 * nfft - 10, nfft, 6)
+        assert np.all(tail[3:] == -150.0) and not np.any(tail[:3] == -150.0)
+        with pytest.raises(IndexError):
+            nat.compute_magnitudes(total_samples * bps - 100, nfft)
+        # the chunked pipeline (file -> pinned ring -> device -> host) across the 2^32 boundary: 40 MiB of
+        # lines with a 4 MiB staging chunk, compared with the mapped-buffer path of spec_waterfall
+        svc.set_option("stage_chunk_mb", 4)
+        try:
+            start = (1 << 32) // bps - 1200 * nfft
+            lines = 2500
+            a = nat.waterfall(start, nfft, lines)
+            b = rec.waterfall(svc, start, nfft, lines)
+            assert np.array_equal(a, b)
+            w0 = (1 << 32) // bps + 4096 * 3 + 5                 # a written window lies inside that span
+            assert not np.all(a == -200.0) and (w0 - start) // nfft < lines
+        finally:
+            svc.set_option("stage_chunk_mb", 64)
+    os.unlink(data_path)

@@ -1,14 +1,23 @@
 #!/bin/bash
-# Development tool: rebuild the library with one set of ablation macros at a time (results are
-# WRONG by construction) and time the headline workload -- shows what each resource costs the
-# kernel.  usage (on the GPU box): [ABLATIONS="A;B C;..."] tools/ablate.sh [bench args]
+# Development tool: build EXPERIMENT libraries with one set of ablation macros each (results are WRONG by
+# construction) and time a workload with every one of them -- shows what each resource costs the kernel.
+# The variants are written beside the product library (lib/libspecgpu_abl<i>.so, selected through
+# SPEC_LIB_VARIANT), never over it.
+#   usage: [ABLATIONS="A;B C;..."] tools/ablate.sh build            (here: hipcc cross-compiles)
+#          [ABLATIONS=...] tools/ablate.sh run [bench args]          (on the GPU box)
 set -e
 cd "$(dirname "$0")/.."
 IFS=';' read -ra VARIANTS <<< "${ABLATIONS:-NONE;NOSTORE;NOBAR;NOLDS;NOFFT;NOFFT NOLDS;NOFFT NOLDS NOSTORE}"
+mode=${1:-run}; shift || true
+i=0
 for abl in "${VARIANTS[@]}"; do
     flags=""
     for a in $abl; do flags="$flags -DSPEC_ABL_$a"; done
-    SPEC_EXTRA_HIPCC_FLAGS="$flags" python -m spectral_analyzer_amd.build --force > /dev/null 2>&1
-    echo "== $abl: $(python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("%.4g lines/s  %.3f ms  frac %.3f  parity_ok=%s" % (d["value"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["parity_spot_check"]["ok"]))')"
+    if [ "$mode" = build ]; then
+        python -m spectral_analyzer_amd.build --variant abl$i -- $flags > /dev/null
+        echo "built abl$i: $abl"
+    else
+        echo "== $abl: $(SPEC_LIB_VARIANT=abl$i python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("%.4g lines/s  %.3f ms  frac %.3f  parity_ok=%s" % (d["value"], d["roofline"]["kernel_ms"], d["roofline"]["frac"], d["parity_spot_check"]["ok"]))')"
+    fi
+    i=$((i+1))
 done
-python -m spectral_analyzer_amd.build --force > /dev/null 2>&1
