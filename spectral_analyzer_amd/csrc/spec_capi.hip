@@ -300,7 +300,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 1 ? 1 : (value > 4 ? 4 : value);
-    else if (!strcmp(key, "large_wg")) c->opt_large_wg = value == 256 ? 256 : 512;
+    else if (!strcmp(key, "large_wg")) c->opt_large_wg = value == 256 ? 256 : (value == 1024 ? 1024 : 512);
     else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
     else if (!strcmp(key, "readahead_lines")) { c->opt_readahead_lines = value < 0 ? 0 : value; c->ra.n = 0; }
@@ -502,6 +502,15 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                                                (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team launch: %s", hipGetErrorString(e));
             done += nl;
+#ifdef SPEC_TEAM_PROF
+            if (const char *path = getenv("SPEC_TEAM_PROF_OUT")) {  // development aid: dump the per-workgroup wait cycles
+                std::vector<unsigned long long> pf(16 * 1024);
+                HIP_TRY(c, hipMemcpyAsync(pf.data(), static_cast<uint8_t *>(c->team_sync) + large_team_prof_offset_bytes(), pf.size() * 8,
+                                          hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (FILE *f = fopen(path, "wb")) { fwrite(pf.data(), 8, pf.size(), f); fclose(f); }
+            }
+#endif
             if (done < n_lines || c->opt_large_team == 2) {
                 // more than one team launch (> 2^30 lines), or no fall-back wanted: check this one now
                 uint32_t aborted = 0;

@@ -312,7 +312,8 @@ __device__ __forceinline__ double db20(cx<double> z) {
 // ln(m inv_i) - ln(inv_i), inv_i = fp64(1 / centre of interval i), -ln(inv_i) tabulated for that ROUNDED inv_i
 // (an identity, no approximation), |m inv_i - 1| < 1/64 so that ln(1 + r) needs the terms up to r^8; 1 / |X| from
 // the fp32 reciprocal square root (1e-7 of a term that is < 1e-7 dB).  Checked on 2e5 random magnitudes in
-// 1e-2 ... 1e18 against 60-digit arithmetic: |error| <= 1.2e-13 dB.  Weaker and huger magnitudes take db20().
+// 1e-2 ... 1e18 against 60-digit arithmetic: |error| <= 1.2e-13 dB.  Weaker magnitudes take the expression as
+// written (square root, + 1e-10, the same table logarithm), huge ones are rescaled first.
 // DB20_TAB: {inv_i, -ln(inv_i)} pairs; the caller copies them to LDS (`tab`) once per workgroup.
 __device__ const double DB20_TAB[64] = {
     0x1.f81f81f81f820p-1, 0x1.fc0a8b0fc03c4p-7, 0x1.e9131abf0b767p-1, 0x1.77458f632dcffp-5,
@@ -332,10 +333,9 @@ __device__ const double DB20_TAB[64] = {
     0x1.0ecf56be69c90p-1, 0x1.4618bc21c5ec2p-1, 0x1.0a6810a6810a7p-1, 0x1.4e7d811b75bb0p-1,
     0x1.0624dd2f1a9fcp-1, 0x1.56bf9d5b3f399p-1, 0x1.0204081020408p-1, 0x1.5ee02a9241676p-1,
 };
-__device__ __forceinline__ double db20_tab(cx<double> z, const double *tab) {
-    const double p = __builtin_fma(z.x, z.x, z.y * z.y);
-    if (!(p > 1e-4 && p < 1e37)) return db20(z);
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(p);
+// ln of a positive normal number by the table (see above)
+__device__ __forceinline__ double ln_tab(double v, const double *tab) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     const int e = (int)(bits >> 52) - 1023;
     const double m = __longlong_as_double((long long)((bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull));
     const int i = (int)(bits >> 47) & 31;
@@ -348,9 +348,29 @@ __device__ __forceinline__ double db20_tab(cx<double> z, const double *tab) {
     q = __builtin_fma(q, r, -1.0 / 4);
     q = __builtin_fma(q, r, 1.0 / 3);
     q = __builtin_fma(q, r, -0.5);
-    const double ln_p = __builtin_fma((double)e, 0x1.62e42fefa39efp-1, li + __builtin_fma(r * r, q, r));
-    const float rs = __frsqrt_rn((float)p);  // 1 / |X|
-    return __builtin_fma(ln_p, 0x1.15f2ced384f29p+2, 0x1.dd8307784b277p-31 * (double)rs);
+    return __builtin_fma((double)e, 0x1.62e42fefa39efp-1, li + __builtin_fma(r * r, q, r));
+}
+// 20 log10(|X| + 1e-10).  Everything inline and short: the library fall-backs of db20() are ~250 instructions per
+// bin, eight times per line they made the row side's loop body larger than the instruction cache it shares.
+__device__ __forceinline__ double db20_tab(cx<double> z, const double *tab) {
+    constexpr double K10 = 0x1.15f2ced384f29p+2;  // 10 / ln 10
+    const double p = __builtin_fma(z.x, z.x, z.y * z.y);
+    // one logarithm, three ways to its argument: result = mul * ln(arg) + add
+    double arg = p, mul = K10, add;
+    if (p > 1e-4 && p < 1e300) {  // |X| > 1e-2: the series form; (float)p overflows to inf for huge p -> correction 0
+        add = 0x1.dd8307784b277p-31 * (double)__frsqrt_rn((float)p);
+    } else if (p <= 1e-4) {  // weak bins, zero and underflow: the expression as written, |X| + 1e-10 in [1e-10, 1e-2]
+        arg = sqrt(p) + 1e-10;
+        mul = 2.0 * K10;
+        add = 0.0;
+        if (arg == 1e-10) return -200.0;  // silence is exactly 20 log10(1e-10)
+    } else {  // |X|^2 beyond 1e300, infinite or NaN: rescale by 2^-600 (|X| + 1e-10 == |X| here)
+        const double xs = z.x * 0x1p-600, ys = z.y * 0x1p-600;
+        arg = __builtin_fma(xs, xs, ys * ys);
+        add = 600.0 * 0x1.8151824c7587fp+2;  // 20 log10(2^600)
+        if (!(arg < 1e300)) return arg;  // +inf stays +inf, NaN stays NaN (Math.log10 does the same)
+    }
+    return __builtin_fma(ln_tab(arg, tab), mul, add);
 }
 
 }  // namespace specgpu

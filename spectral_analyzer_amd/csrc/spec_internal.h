@@ -58,6 +58,7 @@ hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void
 // complex values) without launching.
 size_t large_team_sync_bytes();
 uint32_t large_team_abort_word();
+uint32_t large_team_prof_offset_bytes();  // development builds (-DSPEC_TEAM_PROF): per-workgroup wait cycles behind the block
 hipError_t launch_spectro_team(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2, void *scratch,
                                uint32_t ring, uint32_t *sync, int n_cu, uint32_t *teams_max, bool query_only,
                                hipStream_t s, int wg = 512, uint32_t block = 0);

@@ -127,6 +127,42 @@ template <typename R, int L, int WG> __device__ __forceinline__ void pass2(cx<R>
         for (int r = 0; r < P::R2; ++r) v[s + r * P::S2] = u[r];
     }
 }
+// The same passes with their twiddles held in registers across lines (13 complex values per thread: the table reads
+// of a line were a quarter of its LDS traffic, and the LDS pipe is as busy as the fp64 ALUs in these kernels)
+template <typename R, int L, int WG> struct PassTw {
+    using P = TP<L, WG>;
+    cx<R> w1[7], w2[P::S2][P::R2 - 1];
+    __device__ __forceinline__ void load(int t, const cx<R> *tab) {
+        const int k = t & 7;
+#pragma unroll
+        for (int r = 1; r < 8; ++r) w1[r - 1] = tab[r * k * (P::M / 64)];
+#pragma unroll
+        for (int s = 0; s < P::S2; ++s) {
+            const int k2 = (t + s * P::T) & 63;
+#pragma unroll
+            for (int r = 1; r < P::R2; ++r) w2[s][r - 1] = tab[r * k2];
+        }
+    }
+    __device__ __forceinline__ void pass1(cx<R> (&v)[TE]) const {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) ctw(v[r], w1[r - 1]);
+        dft8(v);
+    }
+    __device__ __forceinline__ void pass2(cx<R> (&v)[TE]) const {
+#pragma unroll
+        for (int s = 0; s < P::S2; ++s) {
+            cx<R> u[P::R2];
+#pragma unroll
+            for (int r = 0; r < P::R2; ++r) u[r] = v[s + r * P::S2];
+#pragma unroll
+            for (int r = 1; r < P::R2; ++r) ctw(u[r], w2[s][r - 1]);
+            dft<R, P::R2>(u);
+#pragma unroll
+            for (int r = 0; r < P::R2; ++r) v[s + r * P::S2] = u[r];
+        }
+    }
+};
+
 // exchanges: after pass 0 butterfly t writes 8 t + r; after pass 1, (t - k) 8 + k + 8 r; reads are t + m T
 template <typename R> __device__ __forceinline__ void xstore0(const cx<R> (&v)[TE], int t, cx<R> *line) {
 #pragma unroll
@@ -162,6 +198,32 @@ template <typename R, int L, int WG> __device__ __forceinline__ void xload(cx<R>
 #define VM_N(N) (N)
 #endif
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_N(N)) : "memory"); }
+
+// development aid (variant builds with -DSPEC_TEAM_PROF): lane 0 of every workgroup adds up shader-clock cycles
+// spent in its waits; eight 64-bit words per workgroup behind the synchronisation block
+#ifdef SPEC_TEAM_PROF
+#define PROF_DECL unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pf_t = 0; (void)pf_t
+#define PROF_T0() (pf_t = __builtin_readcyclecounter())
+#define PROF_ADD(k) (pf[k] += __builtin_readcyclecounter() - pf_t)
+#define PROF_INC(k) (pf[k] += 1)
+#define PROF_PH(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); ph[k] += n__ - ph_t; ph_t = n__; } while (0)
+#define PROF_OUT(role)                                                                                          \
+    do {                                                                                                        \
+        if (threadIdx.x == 0) {                                                                                 \
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.sync + TEAM_SYNC_WORDS) + 16ull * blockIdx.x; \
+            pf[7] = (unsigned long long)(role) | ((unsigned long long)team << 8) | ((unsigned long long)my_lines << 32);   \
+            for (int k = 0; k < 8; ++k) o[k] = pf[k];                                                           \
+            for (int k = 0; k < 8; ++k) o[8 + k] = ph[k];                                                       \
+        }                                                                                                       \
+    } while (0)
+#else
+#define PROF_DECL (void)0
+#define PROF_T0() (void)0
+#define PROF_ADD(k) (void)0
+#define PROF_INC(k) (void)0
+#define PROF_PH(k) (void)0
+#define PROF_OUT(role) (void)0
+#endif
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byte address of a pointer into shared memory
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
@@ -229,8 +291,37 @@ template <typename R> __device__ __forceinline__ void st_slot(cx<R> *p, cx<R> v)
 #ifdef SPEC_ABL_TEAM_NOSTORE
 constexpr int TEAM_NST = 0;
 #else
-constexpr int TEAM_NST = TE;  // output stores per thread and line: one instruction per bin, every format
+#ifdef SPEC_TEAM_SINGLE_STORES
+constexpr int TEAM_NST = TE;      // output stores per thread and line: one instruction per bin, every format
+#else
+constexpr int TEAM_NST = TE / 2;  // output stores per thread and line: one instruction per pair of bins, every format
 #endif
+#endif
+
+// value of one bin (SS:76-82) in the arithmetic of the pipeline
+template <typename R, int FMT> __device__ __forceinline__ R bin_value(cx<R> z, const double *dbt) {
+#ifdef SPEC_ABL_TEAM_NOEPI
+    return z.x;
+#else
+    constexpr bool dbf = FMT == OUT_DB20_F32 || FMT == OUT_DB20_F64;
+    if constexpr (sizeof(R) == 4) return dbf ? db20(z) : z.x * z.x + z.y * z.y;
+    else return dbf ? db20_tab(z, dbt) : __builtin_fma(z.x, z.x, z.y * z.y);
+#endif
+}
+// the value of the neighbouring lane (lane ^ 1): DPP quad permutation, no LDS
+__device__ __forceinline__ float lane_swap1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double lane_swap1(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// two adjacent bins in one store (non-temporal: written once, never read by this launch)
+template <typename T> __device__ __forceinline__ void st_pair(T *p, T lo, T hi) {
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(t2{lo, hi}, reinterpret_cast<t2 *>(p));
+}
 
 // one bin of the result (SS:76-82), non-temporal: written once, never read by this launch
 template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *out, uint64_t idx, cx<R> z, const double *dbt) {
@@ -255,11 +346,13 @@ template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *ou
 // Dynamic LDS of one workgroup.  fp64 (pipelined loads): 256 bytes for the polled counter word, then the landing
 // strips -- WG / 64 waves x TE instructions x 1 KiB -- FIRST, so that every strip's base address fits the 16
 // bits of M0 that are certain to carry it; then line buffers + sub-transform table (MAIN, in cx<R> elements).
-template <typename R, int L1, int L2, int WG> struct TeamLds {
+// DENSE: two workgroups per CU (four waves per SIMD, 128 registers each) that hide latency by occupancy: no
+// landing strips, the plain forms of both sides.
+template <typename R, int L1, int L2, int WG, bool DENSE> struct TeamLds {
     static constexpr size_t A = (size_t)TP<L1, WG>::C * TP<L1, WG>::SL + TP<L1, WG>::M;
     static constexpr size_t B = (size_t)TP<L2, WG>::C * TP<L2, WG>::SL + TP<L2, WG>::M;
     static constexpr size_t MAIN = A > B ? A : B;
-    static constexpr bool PIPE = sizeof(R) == 8;
+    static constexpr bool PIPE = sizeof(R) == 8 && !DENSE;
     static constexpr size_t LAND_BYTES = PIPE ? 256 + (size_t)(WG / 64) * TE * 1024 : 0;
     static constexpr size_t BYTES = LAND_BYTES + MAIN * sizeof(cx<R>);
     // the last strip starts at LAND_BYTES - 1024 behind the kernel's static __shared__ words (< 768 bytes)
@@ -268,11 +361,11 @@ template <typename R, int L1, int L2, int WG> struct TeamLds {
 
 // HALF: hop == N / 2 (BASELINE's 50 % overlap): the lower half of line i + 1 is the upper half of line i and stays
 // in registers.  A template parameter because the pipelined column loop's waits count its load instructions.
-template <typename R, int L1, int L2, bool DIRECT, bool HALF, int WG>
-__global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
+template <typename R, int L1, int L2, bool DIRECT, bool HALF, int WG, bool DENSE>
+__global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const TeamArgs a) {
     using PA = TP<L1, WG>;
     using PB = TP<L2, WG>;
-    using LD = TeamLds<R, L1, L2, WG>;
+    using LD = TeamLds<R, L1, L2, WG, DENSE>;
     constexpr int N1 = PA::M, N2 = PB::M, N = N1 * N2;
     constexpr uint32_t NT = N / (WG * TE);  // tiles per line and step
     static_assert(N2 / PA::C == (int)NT && N1 / PB::C == (int)NT, "tile counts of the two steps match");
@@ -283,7 +376,10 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
     __shared__ int s_flag, s_next;
     __shared__ uint32_t s_info[4];
     __shared__ double s_dbt[64];
-    cx<R> *lds = reinterpret_cast<cx<R> *>(smem + TeamLds<R, L1, L2, WG>::LAND_BYTES);  // line buffers + table
+#ifdef SPEC_TEAM_PROF
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // phase stamps of lane 0 (tools/team_prof.py)
+#endif
+    cx<R> *lds = reinterpret_cast<cx<R> *>(smem + LD::LAND_BYTES);  // line buffers + table
     const int tid = threadIdx.x;
     uint32_t *sync = a.sync;
 
@@ -367,9 +463,16 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
         const uint32_t n2 = c0 + q1;
         const cx<double> w0 = twn[n2 * (uint32_t)t1], wstep = twn[n2 * (uint32_t)PA::T];
         // rest of one line behind the first exchange: pass 2 and the inter-step twiddle
+        PassTw<R, L1, WG> twr;
+        constexpr bool TWREG = !DENSE;  // twiddles in registers where there are 256 of them
+        if constexpr (TWREG) {
+            __syncthreads();  // table visible
+            twr.load(t1, tab);
+        }
         auto finish = [&](cx<R> (&v)[TE]) {
 #ifndef SPEC_ABL_TEAM_NOFFT
-            pass2<R, L1, WG>(v, t1, tab);
+            if constexpr (TWREG) twr.pass2(v);
+            else pass2<R, L1, WG>(v, t1, tab);
 #endif
             cx<double> w = w0;
 #pragma unroll
@@ -409,6 +512,10 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
                 issue_next(1);
                 __syncthreads();  // table visible
                 uint32_t pending = NONE;  // ring slot whose stores are issued but not yet announced
+                PROF_DECL;
+#ifdef SPEC_TEAM_PROF
+                const unsigned long long pf_begin = __builtin_readcyclecounter();
+#endif
                 for (uint32_t i = 0; i < my_lines; ++i) {
                     const uint32_t slot = i % a.ring, round = i / a.ring;
                     cx<R> v[TE];
@@ -420,14 +527,19 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
                     xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
                     // the previous line's stores (and the poll before them) have had this long: wait for them, not
                     // for the NLD loads issued behind them, then announce that line behind the exchange's barrier
+                    PROF_T0();
                     vm_wait<NLD>();
+                    PROF_ADD(1);
+                    PROF_T0();
                     __syncthreads();
+                    PROF_ADD(4);
                     if (tid == 0 && pending != NONE)
                         __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here
                     __syncthreads();
 #ifndef SPEC_ABL_TEAM_NOFFT
-                    pass1<R, L1, WG>(v, t1, tab);
+                    if constexpr (TWREG) twr.pass1(v);
+                    else pass1<R, L1, WG>(v, t1, tab);
 #endif
                     xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
                     // was the slot free when the poll was taken?  (first lines: nobody has used it yet)
@@ -437,7 +549,9 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
                     xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
                     finish(v);
                     // cur <- line i + 1: its rows were requested a whole line ago (behind the last line: unused)
+                    PROF_T0();
                     vm_wait<0>();
+                    PROF_ADD(2);
                     if (HALF && follows(i + 1 < my_lines ? i + 1 : my_lines - 1)) {
 #pragma unroll
                         for (int m = 0; m < NEWH; ++m) { cur[m] = cur[m + NEWH]; cur[m + NEWH] = land[64 * (m + NEWH) + lane]; }
@@ -446,7 +560,10 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
                         for (int m = 0; m < TE; ++m) cur[m] = land[64 * m + lane];
                     }
 #ifndef SPEC_ABL_TEAM_NOWAIT
+                    PROF_T0();
+                    if (!slot_free) PROF_INC(5);
                     if (!slot_free && !team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
+                    PROF_ADD(3);
 #endif
                     if (tid == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, pland_addr);  // before the stores
                     cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
@@ -461,6 +578,10 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
                 vm_wait<0>();
                 __syncthreads();
                 if (tid == 0) __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SPEC_TEAM_PROF
+                pf[0] = __builtin_readcyclecounter() - pf_begin;
+#endif
+                PROF_OUT(1);
                 return;
             }
         }
@@ -510,7 +631,8 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
                 xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here
                 __syncthreads();
 #ifndef SPEC_ABL_TEAM_NOFFT
-                pass1<R, L1, WG>(v, t1, tab);
+                if constexpr (TWREG) twr.pass1(v);
+                else pass1<R, L1, WG>(v, t1, tab);
 #endif
                 xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
                 __syncthreads();
@@ -540,28 +662,58 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
         for (int e = tid; e < N2; e += WG) tab[e] = static_cast<const cx<R> *>(a.tw2)[e];
         __syncthreads();
         cx<R> *line_lds = lds + (size_t)q0 * PB::SL;
+        PassTw<R, L2, WG> twr;
+        constexpr bool TWREG = !DENSE;
+        if constexpr (TWREG) twr.load(t0, tab);
         // the rest of one line behind its first pass and exchange
         auto rest_of_line = [&](cx<R> (&v)[TE], uint32_t line) {
+            PROF_PH(2);  // hand-back, requests for the next tile
             xload<R, L2, WG>(v, t0, line_lds);
             __syncthreads();
+            PROF_PH(3);
 #ifndef SPEC_ABL_TEAM_NOFFT
-            pass1<R, L2, WG>(v, t0, tab);
+            if constexpr (TWREG) twr.pass1(v);
+            else pass1<R, L2, WG>(v, t0, tab);
 #endif
             xstore1<R>(v, t0, line_lds);
             __syncthreads();
+            PROF_PH(4);
             xload<R, L2, WG>(v, t0, line_lds);
 #ifndef SPEC_ABL_TEAM_NOFFT
-            pass2<R, L2, WG>(v, t0, tab);
+            if constexpr (TWREG) twr.pass2(v);
+            else pass2<R, L2, WG>(v, t0, tab);
 #endif
+            PROF_PH(5);
             const uint64_t base = (uint64_t)line * N;
             auto emit = [&](auto fmt_tag) {  // one format per call: the branch on the format is outside the bins
                 constexpr int FMT = decltype(fmt_tag)::value;
+                using TO = std::conditional_t<(FMT >= OUT_DB20_F64), double, float>;
+#if defined(SPEC_TEAM_SINGLE_STORES) || defined(SPEC_ABL_TEAM_NOSTORE)
 #pragma unroll
                 for (int m = 0; m < TE; ++m) {
                     const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + m * PB::T);
                     emit_bin<R, FMT>(a.out, base + ((k + N / 2) & (N - 1)), v[m], s_dbt);  // SS:78
-                    if constexpr (sizeof(R) == 8) __builtin_amdgcn_sched_barrier(0);
                 }
+#else
+                // A thread holds bin k1 = r0 + q0 of eight rows k2; its neighbour (lane ^ 1) holds k1 ^ 1 of the same
+                // rows.  Even lanes store {k1, k1 + 1} of the rows m = 0, 2, 4, 6, odd lanes {k1 - 1, k1} of the rows
+                // m = 1, 3, 5, 7: TE / 2 stores of two bins each instead of TE stores of one (the row side's output
+                // stores were what a line waited for longest).
+                TO d[TE], o[TE];
+#pragma unroll
+                for (int m = 0; m < TE; ++m) d[m] = (TO)bin_value<R, FMT>(v[m], s_dbt);
+#pragma unroll
+                for (int m = 0; m < TE; ++m) o[m] = lane_swap1(d[m]);
+                const bool odd = (q0 & 1) != 0;
+                TO *out = static_cast<TO *>(a.out);
+#pragma unroll
+                for (int pr = 0; pr < TE / 2; ++pr) {
+                    const int me = 2 * pr, mo = 2 * pr + 1;
+                    const uint32_t k2 = (uint32_t)t0 + (uint32_t)(odd ? mo : me) * PB::T;
+                    const uint32_t k = (r0 + ((uint32_t)q0 & ~1u)) + (uint32_t)N1 * k2;  // the even bin of the pair
+                    st_pair<TO>(out + base + ((k + N / 2) & (N - 1)), odd ? o[mo] : d[me], odd ? d[mo] : o[me]);  // SS:78
+                }
+#endif
             };
             asm volatile("" ::: "memory");
             switch (a.out_fmt) {
@@ -571,7 +723,9 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
             default: emit(std::integral_constant<int, OUT_POW_F64>{}); break;
             }
             asm volatile("" ::: "memory");
+            PROF_PH(6);
             __syncthreads();  // the line buffers are rewritten by the next line's first exchange
+            PROF_PH(7);
         };
         auto ready = [&](uint32_t j, uint32_t w) { return j < my_lines && (int32_t)(w - NT * (j / a.ring + 1)) >= 0; };
         if constexpr (LD::PIPE) {
@@ -593,9 +747,18 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
             issue(0);
             issue_poll(1);
             vm_wait<0>();  // the first tile: nothing to overlap with yet
+            PROF_DECL;
+#ifdef SPEC_TEAM_PROF
+            const unsigned long long pf_begin = __builtin_readcyclecounter();
+#endif
             for (uint32_t i = 0; i < my_lines; ++i) {
                 const uint32_t slot = i % a.ring;
+#ifdef SPEC_TEAM_PROF
+                ph_t = __builtin_readcyclecounter();
+#endif
+                PROF_T0();
                 vm_wait<TEAM_NST>();  // tile i and the poll have landed; the stores of line i - 1 fly on
+                PROF_ADD(1);
                 cx<R> v[TE];
 #pragma unroll
                 for (int m = 0; m < TE; ++m) v[m] = land[64 * m + lane];
@@ -604,7 +767,9 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
 #endif
                 xstore0<R>(v, t0, line_lds);
                 if (tid == 0) s_next = ready(i + 1, pland[0]);
+                PROF_PH(0);
                 __syncthreads();
+                PROF_PH(1);
                 // every thread has consumed its slot reads: hand the slot back before the rest of the transform
                 if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef SPEC_ABL_TEAM_NOWAIT
@@ -616,13 +781,22 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
                 issue_poll(i + 2);
                 rest_of_line(v, line_of(i));
                 if (!ahead && i + 1 < my_lines) {  // the column side is not ahead: wait for it here
+                    PROF_T0();
+                    PROF_INC(5);
 #ifndef SPEC_ABL_TEAM_NOWAIT
                     if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
 #endif
+                    PROF_ADD(3);
+                    PROF_T0();
                     issue(i + 1);
                     vm_wait<0>();  // nothing younger to leave in flight on this path
+                    PROF_ADD(2);
                 }
             }
+#ifdef SPEC_TEAM_PROF
+            pf[0] = __builtin_readcyclecounter() - pf_begin;
+#endif
+            PROF_OUT(2);
         } else {
             // ---- plain form (fp32): the next tile requested as soon as the column side has it, loads the compiler knows
             auto load_tile = [&](uint32_t i, cx<R> (&x)[TE]) {
@@ -663,22 +837,22 @@ __global__ __launch_bounds__(WG, 2) void large_team_kernel(const TeamArgs a) {
     }
 }
 
-template <typename R, int L1, int L2, int WG> constexpr size_t team_lds_bytes() { return TeamLds<R, L1, L2, WG>::BYTES; }
+template <typename R, int L1, int L2, int WG, bool DENSE> constexpr size_t team_lds_bytes() { return TeamLds<R, L1, L2, WG, DENSE>::BYTES; }
 
-template <typename R, int L1, int L2, int WG>
+template <typename R, int L1, int L2, int WG, bool DENSE>
 hipError_t launch_team_wg(const TeamArgs &a, int n_cu, uint32_t *teams_max, hipStream_t s, bool query_only) {
-    constexpr size_t lds = team_lds_bytes<R, L1, L2, WG>();
+    constexpr size_t lds = team_lds_bytes<R, L1, L2, WG, DENSE>();
     const bool direct = !a.be && a.kind == (sizeof(R) == 8 ? K_CF64 : K_CF32);
     const bool half = (uint64_t)a.hop * 2 == ((uint64_t)1 << (L1 + L2));
-    auto fn = direct ? (half ? &large_team_kernel<R, L1, L2, true, true, WG> : &large_team_kernel<R, L1, L2, true, false, WG>)
-                     : (half ? &large_team_kernel<R, L1, L2, false, true, WG> : &large_team_kernel<R, L1, L2, false, false, WG>);
+    auto fn = direct ? (half ? &large_team_kernel<R, L1, L2, true, true, WG, DENSE> : &large_team_kernel<R, L1, L2, true, false, WG, DENSE>)
+                     : (half ? &large_team_kernel<R, L1, L2, false, true, WG, DENSE> : &large_team_kernel<R, L1, L2, false, false, WG, DENSE>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int per_cu = 0;
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WG, lds);
     if (e != hipSuccess) return e;
-    // 512 threads of intermediate per CU and no more: two lines in flight per XCD is what its L2 holds
-    constexpr int WANT = 512 / WG;
+    // lines in flight per XCD are bounded by what its L2 holds: one 512-thread workgroup per CU, two when DENSE
+    constexpr int WANT = (DENSE ? 1024 : 512) / WG;
     if (per_cu > WANT) per_cu = WANT;
     if (per_cu < 1) return hipErrorLaunchOutOfResources;
     const uint32_t grid = (uint32_t)per_cu * (uint32_t)n_cu;
@@ -690,13 +864,20 @@ hipError_t launch_team_wg(const TeamArgs &a, int n_cu, uint32_t *teams_max, hipS
 }
 template <typename R, int L1, int L2>
 hipError_t launch_team(const TeamArgs &a, int wg, int n_cu, uint32_t *teams_max, hipStream_t s, bool query_only) {
-    (void)wg;  // 512-thread workgroups (16-wide tiles); 256 measured slower in every configuration
-    return launch_team_wg<R, L1, L2, 512>(a, n_cu, teams_max, s, query_only);
+    // 512-thread workgroups (16-wide tiles; 256 measured slower in every configuration); wg == 1024 selects the
+    // dense form: two of them per CU
+    if (wg == 1024) return launch_team_wg<R, L1, L2, 512, true>(a, n_cu, teams_max, s, query_only);
+    return launch_team_wg<R, L1, L2, 512, false>(a, n_cu, teams_max, s, query_only);
 }
 
 }  // namespace
 
+#ifdef SPEC_TEAM_PROF
+size_t large_team_sync_bytes() { return (size_t)TEAM_SYNC_WORDS * sizeof(uint32_t) + 1024 * 128; }  // + 16 words x 1024 workgroups
+#else
 size_t large_team_sync_bytes() { return (size_t)TEAM_SYNC_WORDS * sizeof(uint32_t); }
+#endif
+uint32_t large_team_prof_offset_bytes() { return TEAM_SYNC_WORDS * (uint32_t)sizeof(uint32_t); }
 uint32_t large_team_abort_word() { return TS_ABORT; }
 
 // Launches the team kernel over all n_lines (one launch).  `sync` must be zeroed (large_team_sync_bytes()) on
@@ -705,7 +886,7 @@ uint32_t large_team_abort_word() { return TS_ABORT; }
 hipError_t launch_spectro_team(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2, void *scratch,
                                uint32_t ring, uint32_t *sync, int n_cu, uint32_t *teams_max, bool query_only,
                                hipStream_t s, int wg, uint32_t block) {
-    if (wg != 256 && wg != 512) return hipErrorInvalidValue;
+    if (wg != 256 && wg != 512 && wg != 1024) return hipErrorInvalidValue;
     TeamArgs a{};
     a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.bps = w.bps; a.kind = w.kind; a.be = w.be;
     a.tw1 = tw1; a.tw2 = tw2; a.twn = w.tw; a.win = w.win; a.scratch = scratch; a.out = w.out; a.out_fmt = w.out_fmt;
