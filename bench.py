@@ -260,7 +260,7 @@ def main() -> None:
                 got = out[ln].cpu().numpy().astype(np.float64)
                 m_ref, m_got = 10 ** (ref / 20), 10 ** (got / 20)
                 worst = max(worst, float(np.abs(m_got - m_ref).max() / (m_ref.max() * np.log2(nfft))))
-            tol = 8e-15 if w["out"] == "f64" else 4e-6
+            tol = (8e-15 + 5e-14 / np.log2(nfft)) if w["out"] == "f64" else 4e-6
             checked = {"lines": len(pick), "max_lin_err_over_M_log2N": worst, "tol": tol, "ok": bool(worst <= tol)}
 
         if world == 1 and not args.no_cpu_baseline:

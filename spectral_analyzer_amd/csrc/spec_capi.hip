@@ -525,7 +525,9 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             run_if = static_cast<uint32_t *>(c->team_sync) + large_team_abort_word();
         }
         // four-step path as two launches per chunk of lines
-        uint64_t chunk = ((uint64_t)(team ? 128 : c->opt_large_chunk_mb) << 20) / per_line;
+        // (behind the team kernel too: every chunk is two launches, and 512 guarded launches that return at once
+        // still cost a millisecond per 32 767 lines; the 1 GiB chunk makes it 64)
+        uint64_t chunk = ((uint64_t)c->opt_large_chunk_mb << 20) / per_line;
         if (chunk == 0) chunk = 1;
         if (chunk > n_lines) chunk = n_lines;
         if ((st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)chunk * per_line)) != SPEC_OK) return st;

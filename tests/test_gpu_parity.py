@@ -11,8 +11,9 @@ fp32 pipeline (reference is fp64):  with M = max_k |X[k]| of the line,
   state 2e-3 dB down to 1e-4 M, written before anything was measured; the two-tier statement
   above is the one the build holds, and test_observed_fp32_error_per_tier prints the maxima)
 fp64 pipeline (DB20_F64 / cf64), the same two forms with fp64's epsilon:
-    * every bin with |X| >= 1e-9 * M:  | |X|_gpu - |X|_ref |  <=  8e-15 * M * log2(N)
-      (= the fp32 bound scaled by eps64 / eps32)
+    * every bin with |X| >= 1e-9 * M:  | |X|_gpu - |X|_ref |  <=  (8e-15 * log2(N) + 5e-14) * M
+      (the fp32 bound scaled by eps64 / eps32, plus what the dB value itself can carry: the fp64 log epilogues
+      are good to 3e-13 dB = 3.5e-14 relative, and the comparison goes through the dB values)
     * bins with |X| >= 1e-5 * M:       | dB_gpu - dB_ref |    <=  1e-9 dB
   SURVEY 8(c) states the 1e-9 dB down to 1e-9 M; no fp64 transform can deliver that: both the oracle
   and the GPU carry an absolute error of a few 1e-16 M per bin, which on a bin of 1e-6 M is already
@@ -49,8 +50,9 @@ def check_fp64(db_gpu, db_ref):
     mag_g = 10.0 ** (db_gpu.astype(np.float64) / 20.0)
     M = mag_r.max(axis=1, keepdims=True)
     seen = mag_r >= 1e-9 * M            # below that the +1e-10 of SS:81 takes over
-    lin = (np.abs(mag_g - mag_r) / (M * np.log2(max(nfft, 2))))[seen]
-    assert lin.max() <= 8e-15, "fp64 linear error %.3g > 8e-15 M log2 N" % lin.max()
+    lin = (np.abs(mag_g - mag_r) / M)[seen]
+    tol = 8e-15 * np.log2(max(nfft, 2)) + 5e-14
+    assert lin.max() <= tol, "fp64 linear error %.3g M > %.3g M" % (lin.max(), tol)
     err = np.abs(db_gpu - db_ref)[mag_r >= 1e-5 * M]
     assert err.max() <= 1e-9, "fp64 dB error %.3g" % err.max()
 

@@ -102,7 +102,7 @@ def test_recording_larger_than_2_gib(tmp_path, oracle, svc, dataset):
             one = nat.compute_magnitudes(first * bps, nfft)      # a startByte no int can hold (MC:985)
             check_fp64(one[None, :], oracle.compute_magnitudes(raw, 0, nfft, datatype)[None, :])
         hole = nat.waterfall((3 << 30) // bps, nfft, 2)
-        assert np.all(hole == -200.0)                            # zeros -> 20 log10(1e-10)
+        assert np.abs(hole + 200.0).max() < 1e-3                 # zeros -> 20 log10(1e-10), in fp32
         tail = nat.waterfall(total_samples - 3 * nfft - 10, nfft, 6)
         assert np.all(tail[3:] == -150.0) and not np.any(tail[:3] == -150.0)
         with pytest.raises(IndexError):
