@@ -292,7 +292,7 @@ def main() -> None:
         value = total_lines * args.steps / elapsed
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.log2_samples is None and args.n_psd is None:
+        if os.path.exists(tpath) and args.log2_samples is None and args.n_psd is None and not args.opt:
             try:
                 traffic = json.load(open(tpath)).get(args.workload)
             except Exception:

@@ -115,6 +115,8 @@ void *spec_stream(const spec_ctx *ctx);
  *   "force_generic" = 1  route every request through the generic (scalar-math) kernels
  *   "lines_per_wg"  = n  consecutive lines (Welch: segments) walked by one sub-line / workgroup (0 = automatic)
  *   "large_chunk_mb" = m scratch size of the two-launch four-step path (nfft >= 32768; default 1024 MiB)
+ *   "rec_pread" = 0 | 1   recordings opened by path: 0 (default) stage from the library's own mapping of the file,
+ *                     1 = pread into a pinned two-slot ring (one more host copy; for files that cannot be mapped)
  *   "large_team" = 0 | 1 | 2   lines longer than the LDS holds (fp32 nfft >= 32768, fp64 nfft >= 16384): 1 (default)
  *                     = one persistent launch that keeps the intermediate in each XCD's L2, for calls of >= 64 lines,
  *                     with the two-launch path behind it as a guarded fall-back; 0 = two-launch path only; 2 = the
@@ -185,8 +187,10 @@ spec_status spec_waterfall(spec_ctx *ctx, const void *iq, int iq_on_device, uint
  * (MainController.java:985, SS:33), so only the first 2 GiB of a recording can be shown.  A
  * spec_recording is the data file itself -- `data_path` as SigMfHelper resolves it (core:dataset or
  * the .sigmf-data sibling, SMH:49-57), `header_bytes` = captures[0] core:header_bytes (SMH:60-67) --
- * with 64-bit offsets and no size limit.  The library reads the slices it needs with pread into a
- * pinned two-slot ring that feeds the same two-deep device pipeline as spec_waterfall. */
+ * with 64-bit offsets and no size limit.  The library maps the whole file itself (64-bit length) and
+ * feeds the same two-deep device pipeline as spec_waterfall from the mapping; where the mapping is
+ * refused, or with spec_set_option("rec_pread", 1), it reads the slices it needs with pread into a
+ * pinned two-slot ring instead. */
 typedef struct spec_recording spec_recording;
 spec_status spec_open_recording(spec_ctx *ctx, const char *data_path, uint64_t header_bytes,
                                 spec_recording **out);

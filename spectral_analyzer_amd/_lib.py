@@ -75,6 +75,14 @@ def load() -> C.CDLL:
             raise ImportError(
                 "libspecgpu.so is not built (%s). Run `python -m spectral_analyzer_amd.build`; "
                 "there is no CPU fallback." % LIB_PATH)
+        # PyTorch's wheel carries its own ROCm runtime libraries.  If libspecgpu.so (linked against the system
+        # ROCm's libamdhip64) is loaded first, torch later brings in a second HIP runtime and finds no GPU
+        # ("No HIP GPUs are available").  Loading torch first makes both use the one runtime; hosts without
+        # torch (C, C++, Java) are not affected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as e:  # missing ROCm runtime etc.

@@ -311,7 +311,7 @@ __device__ __forceinline__ double db20(cx<double> z) {
 // next term of the series is < 5e-16 dB), p = |X|^2 = m 2^e with m in [1, 2) cut into 32 intervals: ln m =
 // ln(m inv_i) - ln(inv_i), inv_i = fp64(1 / centre of interval i), -ln(inv_i) tabulated for that ROUNDED inv_i
 // (an identity, no approximation), |m inv_i - 1| < 1/64 so that ln(1 + r) needs the terms up to r^8; 1 / |X| from
-// the fp32 reciprocal square root (1e-7 of a term that is < 1e-7 dB).  Checked on 2e5 random magnitudes in
+// the hardware reciprocal-square-root estimate (1e-7 of a term that is < 1e-7 dB).  Checked on 2e5 random magnitudes in
 // 1e-2 ... 1e18 against 60-digit arithmetic: |error| <= 1.2e-13 dB.  Weaker magnitudes take the expression as
 // written (square root, + 1e-10, the same table logarithm), huge ones are rescaled first.
 // DB20_TAB: {inv_i, -ln(inv_i)} pairs; the caller copies them to LDS (`tab`) once per workgroup.
@@ -357,8 +357,9 @@ __device__ __forceinline__ double db20_tab(cx<double> z, const double *tab) {
     const double p = __builtin_fma(z.x, z.x, z.y * z.y);
     // one logarithm, three ways to its argument: result = mul * ln(arg) + add
     double arg = p, mul = K10, add;
-    if (p > 1e-4 && p < 1e300) {  // |X| > 1e-2: the series form; (float)p overflows to inf for huge p -> correction 0
-        add = 0x1.dd8307784b277p-31 * (double)__frsqrt_rn((float)p);
+    if (p > 1e-4 && p < 1e300) {  // |X| > 1e-2: the series form.  1 / |X| from the hardware estimate (v_rsq_f64, one
+        // quarter-rate instruction; two conversions around v_rsq_f32 cost three): ~1e-8 of a term below 1e-7 dB
+        add = 0x1.dd8307784b277p-31 * __builtin_amdgcn_rsq(p);
     } else if (p <= 1e-4) {  // weak bins, zero and underflow: the expression as written, |X| + 1e-10 in [1e-10, 1e-2]
         arg = sqrt(p) + 1e-10;
         mul = 2.0 * K10;

@@ -113,11 +113,17 @@ def test_recording_larger_than_2_gib(tmp_path, oracle, svc, dataset):
         try:
             start = (1 << 32) // bps - 1200 * nfft
             lines = 2500
-            a = nat.waterfall(start, nfft, lines)
-            b = rec.waterfall(svc, start, nfft, lines)
-            assert np.array_equal(a, b)
+            a = nat.waterfall(start, nfft, lines)                # the library's own mapping of the file
+            b = rec.waterfall(svc, start, nfft, lines)           # the caller's mapping (numpy.memmap)
+            svc.set_option("rec_pread", 1)
+            c = nat.waterfall(start, nfft, lines)                # pread into the pinned ring
+            one = nat.compute_magnitudes(((1 << 31) // bps + 77) * bps, nfft)
+            svc.set_option("rec_pread", 0)
+            assert np.array_equal(a, b) and np.array_equal(a, c)
+            assert np.array_equal(one, nat.compute_magnitudes(((1 << 31) // bps + 77) * bps, nfft))
             w0 = (1 << 32) // bps + 4096 * 3 + 5                 # a written window lies inside that span
             assert not np.all(a == -200.0) and (w0 - start) // nfft < lines
         finally:
             svc.set_option("stage_chunk_mb", 64)
+            svc.set_option("rec_pread", 0)
     os.unlink(data_path)
