@@ -64,9 +64,9 @@ class SigMfRecording:
 
     # -- the same through the library's own file reader (include/specgpu.h, spec_open_recording) --------
     def open_native(self, svc: SpectralService) -> "NativeRecording":
-        """The data file handed to the library by PATH (``spec_open_recording``): it preads the slices it
-        needs into a pinned ring, 64-bit offsets, no mapping -- what a Java host uses instead of the
-        <= 2 GiB ``MappedByteBuffer`` of ``SigMfHelper.java:78-84``."""
+        """The data file handed to the library by PATH (``spec_open_recording``): the library maps the whole
+        file itself (64-bit length; option ``rec_pread`` = 1: preads the slices into a pinned ring instead) --
+        what a Java host uses instead of the <= 2 GiB ``MappedByteBuffer`` of ``SigMfHelper.java:78-84``."""
         return NativeRecording(svc, self)
 
 
