@@ -52,11 +52,12 @@ template <int L, int WG> struct TP {
 enum : uint32_t {
     TS_TOTAL = 0,       // workgroups registered
     TS_ABORT = 16,      // set by a workgroup whose wait timed out (own 64-byte line)
-    TS_XCC = 32,        // [8] tickets per XCD, 16 words apart
+    TS_XCC = 32,        // [8] tickets per XCD, 16 words apart (paired roles: column tickets at +0, row tickets at +1)
     TS_RING = 32 + 8 * 16,  // per team and ring slot: doneA, doneB (16 words apart)
 };
 constexpr uint32_t TEAM_MAX_TEAMS = 64;
-constexpr uint32_t TEAM_SYNC_WORDS = TS_RING + TEAM_MAX_TEAMS * TEAM_RING_MAX * 2 * 16;
+constexpr uint32_t TS_CU = TS_RING + TEAM_MAX_TEAMS * TEAM_RING_MAX * 2 * 16;  // [8 XCDs][256 CU keys] arrivals per CU
+constexpr uint32_t TEAM_SYNC_WORDS = TS_CU + 8 * 256;
 
 struct TeamArgs {
     const uint8_t *iq;  // first byte of line 0
@@ -212,6 +213,12 @@ template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_wai
         if (threadIdx.x == 0) {                                                                                 \
             unsigned long long *o = reinterpret_cast<unsigned long long *>(a.sync + TEAM_SYNC_WORDS) + 16ull * blockIdx.x; \
             pf[7] = (unsigned long long)(role) | ((unsigned long long)team << 8) | ((unsigned long long)my_lines << 32);   \
+            {                                                                                                   \
+                uint32_t hw__, xc__;                                                                            \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                             \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc__));                            \
+                pf[6] = hw__ | ((unsigned long long)xc__ << 32);                                                \
+            }                                                                                                   \
             for (int k = 0; k < 8; ++k) o[k] = pf[k];                                                           \
             for (int k = 0; k < 8; ++k) o[8 + k] = ph[k];                                                       \
         }                                                                                                       \
@@ -354,7 +361,8 @@ template <typename R, int L1, int L2, int WG, bool DENSE> struct TeamLds {
     static constexpr size_t MAIN = A > B ? A : B;
     static constexpr bool PIPE = sizeof(R) == 8 && !DENSE;
     static constexpr size_t LAND_BYTES = PIPE ? 256 + (size_t)(WG / 64) * TE * 1024 : 0;
-    static constexpr size_t BYTES = LAND_BYTES + MAIN * sizeof(cx<R>);
+    static constexpr size_t DBT_OFF = LAND_BYTES + MAIN * sizeof(cx<R>);  // table of the fp64 dB epilogue (spec_fft.h)
+    static constexpr size_t BYTES = DBT_OFF + DB20_TAB_DOUBLES * sizeof(double);
     // the last strip starts at LAND_BYTES - 1024 behind the kernel's static __shared__ words (< 768 bytes)
     static_assert(LAND_BYTES == 0 || LAND_BYTES - 1024 + 767 <= 65535, "strip bases must stay below 64 KiB");
 };
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_flag, s_next;
     __shared__ uint32_t s_info[4];
-    __shared__ double s_dbt[64];
+    double *s_dbt = reinterpret_cast<double *>(smem + LD::DBT_OFF);
 #ifdef SPEC_TEAM_PROF
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // phase stamps of lane 0 (tools/team_prof.py)
 #endif
@@ -384,16 +392,32 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     uint32_t *sync = a.sync;
 
     // ---- registration: which XCD am I on, which ticket do I hold there --------------------------------
+    // PAIRED (two 256-thread workgroups per CU): the first workgroup to arrive on a CU takes a column role, the
+    // second a row role, so that every CU carries one of each -- the row side has half again as much arithmetic per
+    // line, and two workgroups with barriers of their own fill each other's LDS and barrier phases.  Which CU:
+    // HW_REG_HW_ID bits 8..15 (CU, shader array, shader engine); were that key ever shared by two CUs the roles
+    // would still come out in equal numbers, only the pairing would be imperfect.
+    constexpr bool PAIRED = WG == 256;
     if (tid == 0) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;
-        const uint32_t ticket = __hip_atomic_fetch_add(sync + TS_XCC + 16 * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t ticket;
+        if constexpr (PAIRED) {
+            uint32_t hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            const uint32_t key = (hwid >> 8) & 0xFFu;
+            const uint32_t role = __hip_atomic_fetch_add(sync + TS_CU + 256 * xcc + key, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+            ticket = __hip_atomic_fetch_add(sync + TS_XCC + 16 * xcc + role, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_info[2] = role;
+        } else {
+            ticket = __hip_atomic_fetch_add(sync + TS_XCC + 16 * xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __hip_atomic_fetch_add(sync + TS_TOTAL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_info[0] = xcc;
         s_info[1] = ticket;
     }
-    if (tid < 64) s_dbt[tid] = DB20_TAB[tid];
+    if (tid < DB20_TAB_DOUBLES) s_dbt[tid] = DB20_TAB[tid];
     __syncthreads();
     if (!team_wait(sync + TS_TOTAL, gridDim.x, sync, &s_flag)) return;
     // everybody has registered: the tickets per XCD are final
@@ -401,19 +425,33 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         const uint32_t xcc = s_info[0], ticket = s_info[1];
         uint32_t teams_before = 0, teams_total = 0, mine = 0;
         for (uint32_t x = 0; x < 8; ++x) {
-            const uint32_t t = ld_sc1(sync + TS_XCC + 16 * x) / TEAM;
+            uint32_t t;
+            if constexpr (PAIRED) {  // a team needs NT members of either role
+                const uint32_t nc = ld_sc1(sync + TS_XCC + 16 * x), nr = ld_sc1(sync + TS_XCC + 16 * x + 1);
+                t = (nc < nr ? nc : nr) / NT;
+            } else {
+                t = ld_sc1(sync + TS_XCC + 16 * x) / TEAM;
+            }
             if (x < xcc) teams_before += t;
             if (x == xcc) mine = t;
             teams_total += t;
         }
-        const uint32_t local_team = ticket / TEAM;
+        uint32_t local_team, member;
+        if constexpr (PAIRED) {
+            local_team = ticket / NT;
+            member = s_info[2] * NT + ticket % NT;
+        } else {
+            local_team = ticket / TEAM;
+            member = ticket % TEAM;
+        }
+        s_info[1] = member;
         s_info[2] = local_team < mine ? teams_before + local_team : NONE;  // left over on this XCD: no team
         s_info[3] = teams_total;
         if (teams_total == 0 || teams_total > TEAM_MAX_TEAMS)  // nobody could form a team: the host falls back
             __hip_atomic_store(sync + TS_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const uint32_t team = s_info[2], n_teams = s_info[3], member = s_info[1] % TEAM;
+    const uint32_t team = s_info[2], n_teams = s_info[3], member = s_info[1];
     if (team == NONE || n_teams == 0 || n_teams > TEAM_MAX_TEAMS) return;
     // Which lines are this team's.  block == 0: one contiguous range per team.  Otherwise blocks of `block`
     // consecutive lines are dealt to the teams in turn: at any moment the teams then work within a few MiB of
@@ -666,18 +704,26 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         constexpr bool TWREG = !DENSE;
         if constexpr (TWREG) twr.load(t0, tab);
         // the rest of one line behind its first pass and exchange
-        auto rest_of_line = [&](cx<R> (&v)[TE], uint32_t line) {
-            PROF_PH(2);  // hand-back, requests for the next tile
+        // `between(stage)`, stage 0 .. 3: the caller's requests for the next tile, a quarter of them in front of each
+        // stretch of arithmetic instead of all at once (eight 1 KiB requests per wave keep the texture addresser busy
+        // for ~130 cycles per wave, ~1000 per workgroup, during which nobody computed); stage 4: between the
+        // epilogue's arithmetic and its stores (the caller's poll of the ring: as late as the order of the waits allows)
+        auto rest_of_line = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
+            between(std::integral_constant<int, 0>{});
+            PROF_PH(2);  // hand-back, first requests for the next tile
             xload<R, L2, WG>(v, t0, line_lds);
             __syncthreads();
             PROF_PH(3);
+            between(std::integral_constant<int, 1>{});
 #ifndef SPEC_ABL_TEAM_NOFFT
             if constexpr (TWREG) twr.pass1(v);
             else pass1<R, L2, WG>(v, t0, tab);
 #endif
+            between(std::integral_constant<int, 2>{});
             xstore1<R>(v, t0, line_lds);
             __syncthreads();
             PROF_PH(4);
+            between(std::integral_constant<int, 3>{});
             xload<R, L2, WG>(v, t0, line_lds);
 #ifndef SPEC_ABL_TEAM_NOFFT
             if constexpr (TWREG) twr.pass2(v);
@@ -689,6 +735,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 constexpr int FMT = decltype(fmt_tag)::value;
                 using TO = std::conditional_t<(FMT >= OUT_DB20_F64), double, float>;
 #if defined(SPEC_TEAM_SINGLE_STORES) || defined(SPEC_ABL_TEAM_NOSTORE)
+                between(std::integral_constant<int, 4>{});
 #pragma unroll
                 for (int m = 0; m < TE; ++m) {
                     const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + m * PB::T);
@@ -700,12 +747,21 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 // m = 1, 3, 5, 7: TE / 2 stores of two bins each instead of TE stores of one (the row side's output
                 // stores were what a line waited for longest).
                 TO d[TE], o[TE];
+#ifndef SPEC_ABL_TEAM_NOEPI
+                if constexpr (FMT == OUT_DB20_F64 && sizeof(R) == 8) {
+                    db20_tab_n<TE>(v, s_dbt, d);
+                } else
+#endif
+                {
 #pragma unroll
-                for (int m = 0; m < TE; ++m) d[m] = (TO)bin_value<R, FMT>(v[m], s_dbt);
+                    for (int m = 0; m < TE; ++m) d[m] = (TO)bin_value<R, FMT>(v[m], s_dbt);
+                }
 #pragma unroll
                 for (int m = 0; m < TE; ++m) o[m] = lane_swap1(d[m]);
                 const bool odd = (q0 & 1) != 0;
                 TO *out = static_cast<TO *>(a.out);
+                asm volatile("" ::: "memory");
+                between(std::integral_constant<int, 4>{});
 #pragma unroll
                 for (int pr = 0; pr < TE / 2; ++pr) {
                     const int me = 2 * pr, mo = 2 * pr + 1;
@@ -733,11 +789,13 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             // Per line: [tile of line i + 1 into the strips, if the column side has it (poll taken one line earlier)]
             // [poll for line i + 2] [the 8 output stores of line i].  The tile is read at the top of the next
             // iteration behind vm_wait<8>: the loads and the poll are older than the stores, the stores stay in flight.
-            auto issue = [&](uint32_t i) {
+            auto issue_part = [&](uint32_t i, auto from_tag, auto to_tag) {
                 const cx<R> *src = slots + (uint64_t)(i % a.ring) * N + r0 + q0;
 #pragma unroll
-                for (int m = 0; m < TE; ++m) glds16<1>(src + (uint64_t)(t0 + m * PB::T) * N1, land_addr + 1024u * m);  // [n2][k1]
+                for (int m = decltype(from_tag)::value; m < decltype(to_tag)::value; ++m)
+                    glds16<1>(src + (uint64_t)(t0 + m * PB::T) * N1, land_addr + 1024u * m);  // [n2][k1]
             };
+            auto issue = [&](uint32_t i) { issue_part(i, std::integral_constant<int, 0>{}, std::integral_constant<int, TE>{}); };
             auto issue_poll = [&](uint32_t j) {  // doneA of line j's slot (lane 0)
                 if (tid == 0 && j < my_lines) glds4_sc1(ring + 32 * (j % a.ring), pland_addr);
             };
@@ -777,9 +835,21 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #else
                 const bool ahead = s_next != 0;
 #endif
-                if (ahead) issue(i + 1);
+#ifdef SPEC_TEAM_EARLY_POLL
                 issue_poll(i + 2);
-                rest_of_line(v, line_of(i));
+#endif
+                rest_of_line(v, line_of(i), [&](auto stage) {  // every request is older than the line's output stores
+                    constexpr int ST = decltype(stage)::value, Q = TE / 4;
+                    if constexpr (ST < 4) {
+                        if (ahead) issue_part(i + 1, std::integral_constant<int, ST * Q>{}, std::integral_constant<int, ST * Q + Q>{});
+                    } else {
+                        // has the column side stored line i + 2?  Asked as late as possible: the answer is read at the
+                        // top of the next line, and a "not yet" costs that line a blocking wait and an exposed tile read
+#ifndef SPEC_TEAM_EARLY_POLL
+                        issue_poll(i + 2);
+#endif
+                    }
+                });
                 if (!ahead && i + 1 < my_lines) {  // the column side is not ahead: wait for it here
                     PROF_T0();
                     PROF_INC(5);
@@ -825,7 +895,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool ahead = s_next != 0;
                 if (ahead) load_tile(i + 1, nxt);
-                rest_of_line(v, line_of(i));
+                rest_of_line(v, line_of(i), [](auto) {});
                 if (!ahead && i + 1 < my_lines) {
 #ifndef SPEC_ABL_TEAM_NOWAIT
                     if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
@@ -864,9 +934,10 @@ hipError_t launch_team_wg(const TeamArgs &a, int n_cu, uint32_t *teams_max, hipS
 }
 template <typename R, int L1, int L2>
 hipError_t launch_team(const TeamArgs &a, int wg, int n_cu, uint32_t *teams_max, hipStream_t s, bool query_only) {
-    // 512-thread workgroups (16-wide tiles; 256 measured slower in every configuration); wg == 1024 selects the
-    // dense form: two of them per CU
+    // 512: one workgroup per CU, 16-wide tiles.  256: two per CU, 8-wide tiles, one of either role on every CU.
+    // 1024 selects the dense form: two 512-thread workgroups per CU
     if (wg == 1024) return launch_team_wg<R, L1, L2, 512, true>(a, n_cu, teams_max, s, query_only);
+    if (wg == 256) return launch_team_wg<R, L1, L2, 256, false>(a, n_cu, teams_max, s, query_only);
     return launch_team_wg<R, L1, L2, 512, false>(a, n_cu, teams_max, s, query_only);
 }
 

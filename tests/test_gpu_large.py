@@ -10,13 +10,17 @@ from test_gpu_parity import check_fp32, check_fp64
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def team(svc):
-    """large_team = 2: the team kernel for any number of lines, no fall-back -- a timed-out wait is an error."""
+@pytest.fixture(params=[512, 256], ids=["wg512", "wg256"])
+def team(svc, request):
+    """large_team = 2: the team kernel for any number of lines, no fall-back -- a timed-out wait is an error.
+    Both geometries: one 512-thread workgroup per CU (16-wide tiles), two 256-thread workgroups per CU (8-wide
+    tiles, one of either role on every CU)."""
     svc.set_option("large_team", 2)
+    svc.set_option("large_wg", request.param)
     yield svc
     svc.set_option("large_team", 1)
-    svc.set_option("large_ring", 2)
+    svc.set_option("large_ring", 3)
+    svc.set_option("large_wg", 0)
 
 
 CASES = [  # datatype, nfft, hop, n_lines, window, fp64 output

@@ -7,7 +7,8 @@ Needs the profiling variant of the library:
     python tools/team_prof.py /tmp/prof.bin
 Words per workgroup (shader-clock cycles of lane 0): 0 loop total, 1 counted wait at the top (column side: for the
 previous line's stores; row side: for the tile), 2 wait for the prefetched rows / fall-back tile, 3 blocking ring
-waits, 4 column side: first barrier, 5 number of blocking ring waits, 7 role | team << 8 | lines << 32."""
+waits, 4 column side: first barrier, 5 number of blocking ring waits, 6 HW_REG_HW_ID | XCC_ID << 32,
+7 role | team << 8 | lines << 32."""
 import sys
 import numpy as np
 
@@ -34,3 +35,13 @@ if len(s):
     print("row side phases (cycles per line, lane 0 of each workgroup):")
     for k, nm in enumerate(names):
         print("   %-40s %7.0f" % (nm, (s[:, 8 + k] / n).mean()))
+
+# who shares a CU: HW_ID bits 8..15 (CU, shader array, shader engine) within an XCD
+from collections import defaultdict
+cu = defaultdict(list)
+for row in a:
+    cu[(int(row[6] >> 32) & 15, int(row[6] >> 8) & 0xFF)].append(int(row[7]) & 0xFF)
+kinds = defaultdict(int)
+for k, v in cu.items():
+    kinds[tuple(sorted(v))] += 1
+print("CUs by the roles of their workgroups (1 column, 2 row):", dict(kinds), " distinct (XCD, CU) keys:", len(cu))
