@@ -30,11 +30,18 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
     const v2d *__restrict__ tw = static_cast<const v2d *>(a.tw);
 
     if constexpr (PL::NPASS > 2) fill_tables<L, 1>(tab, tw, tid);
+    // table of the dB epilogue's logarithm (spec_fft.h, db20_tab_n) behind the twiddle tables
+    const double *dbt = reinterpret_cast<const double *>(smem + p2_lds_bytes<L, 16>());
+    if constexpr (MODE == 0) {
+        double *dbt_w = reinterpret_cast<double *>(smem + p2_lds_bytes<L, 16>());
+        for (int e = tid; e < DB20_TAB_DOUBLES; e += PL::WG) dbt_w[e] = DB20_TAB[e];
+    }
+    (void)dbt;
     v2d twl[16];
 #pragma unroll
     for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
     const double *win = static_cast<const double *>(a.win);
-    if constexpr (PL::NPASS > 2) __syncthreads();
+    if constexpr (PL::NPASS > 2 || MODE == 0) __syncthreads();
 
     const uint32_t unit = blockIdx.x / a.wgs_per_unit, wg = blockIdx.x % a.wgs_per_unit;
     const uint32_t line0 = wg * (uint32_t)PL::LPW * a.run;
@@ -109,18 +116,33 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
             continue;
         }
         // out[(k + N/2) mod N] = 20 log10(|X_k| + 1e-10)  (SS:78-81), or |X_k|^2
+        // (the table logarithm of spec_fft.h, four bins at a time: the series form without a branch per bin)
         const int out_off = (int)(line * (uint32_t)N * esz);
+        constexpr int G = 4;
 #pragma unroll
-        for (int m = 0; m < E; ++m) {
-            const double val = out_db ? db20(cx<double>{v[m].x * scale, v[m].y * scale}) : pk_norm(v[m]) * (scale * scale);
-            const int so = out_off + ((m + E / 2) & (E - 1)) * T * (int)esz;
-            if (out64) {
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)bits, (uint32_t)(bits >> 32)}, dst, ovoff, so, ST_AUX);
+        for (int g = 0; g < E; g += G) {
+            double val[G];
+            if (out_db) {
+                cx<double> z[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) z[j] = cx<double>{v[g + j].x * scale, v[g + j].y * scale};
+                db20_tab_n<G>(z, dbt, val);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)val), dst, ovoff, so, ST_AUX);
+#pragma unroll
+                for (int j = 0; j < G; ++j) val[j] = pk_norm(v[g + j]) * (scale * scale);
             }
-            __builtin_amdgcn_sched_barrier(0);  // one bin's sqrt / log series at a time
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int m = g + j;
+                const int so = out_off + ((m + E / 2) & (E - 1)) * T * (int)esz;
+                if (out64) {
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(val[j]);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)bits, (uint32_t)(bits >> 32)}, dst, ovoff, so, ST_AUX);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)val[j]), dst, ovoff, so, ST_AUX);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one group's logarithms at a time (registers)
         }
     }
     if constexpr (MODE == 1) {  // one fp64 slab per sub-line (zeros for idle ones), unshifted bins
@@ -133,7 +155,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
 template <int L, int KIND, int SH, bool HAS_WIN, bool BE = false, int MODE = 0>
 hipError_t v3d_launch1(const V2Args &a, hipStream_t s) {
     using PL = Plan2<L>;
-    constexpr size_t lds = p2_lds_bytes<L, 16>();
+    constexpr size_t lds = p2_lds_bytes<L, 16>() + (MODE == 0 ? DB20_TAB_DOUBLES * sizeof(double) : 0);
     auto kern = v3d_kernel<L, KIND, SH, HAS_WIN, BE, MODE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
