@@ -10,16 +10,22 @@ tag, rnd, workload, needle = sys.argv[1:5]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, workload)))
 rows = list(csv.DictReader(open(stats)))
 main = [r for r in rows if needle in r["Name"]][0]
-trace = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
+trace = max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
 durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace)) if r["Kernel_Name"] == main["Name"]]
 bench = json.load(open(os.path.join(src, "bench_under_prof.json")))
 timed = durs[-bench["steps"]:]
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+# one file per pass: gpurun merges a call's output into what earlier calls left in gpurun_out/, keep the newest
+newest = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    d = os.path.dirname(os.path.dirname(f))
+    if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+        newest[d] = f
+for f in newest.values():
     for r in csv.DictReader(open(f)):
         pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in pmc.items()}
