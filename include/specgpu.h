@@ -115,6 +115,8 @@ void *spec_stream(const spec_ctx *ctx);
  *   "force_generic" = 1  route every request through the generic (scalar-math) kernels
  *   "lines_per_wg"  = n  consecutive lines (Welch: segments) walked by one sub-line / workgroup (0 = automatic)
  *   "large_chunk_mb" = m scratch size of the two-launch four-step path (nfft >= 32768; default 1024 MiB)
+ *   "welch_two_pass" = 1 always sum Welch partial slabs in a second launch (default 0: batches of >= two PSDs per CU
+ *                     with nfft >= 2048 are finished by the workgroup that walked the PSD's segments)
  *   "rec_pread" = 0 | 1   recordings opened by path: 0 (default) stage from the library's own mapping of the file,
  *                     1 = pread into a pinned two-slot ring (one more host copy; for files that cannot be mapped)
  *   "large_team" = 0 | 1 | 2   lines longer than the LDS holds (fp32 nfft >= 32768, fp64 nfft >= 16384): 1 (default)

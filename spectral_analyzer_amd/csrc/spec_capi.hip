@@ -59,6 +59,7 @@ struct spec_ctx {
     // tuning / testing knobs (spec_set_option)
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
     int64_t opt_large_team = 1, opt_large_ring = 3, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
+    int64_t opt_welch_two_pass = 0;
     int n_cu = 256;
     // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
     // them against the compute stream, created on first use
@@ -302,6 +303,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "large_chunk_mb")) c->opt_large_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "rec_pread")) c->opt_rec_pread = value != 0;
+    else if (!strcmp(key, "welch_two_pass")) c->opt_welch_two_pass = value != 0;
     else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 1 ? 1 : (value > 4 ? 4 : value);
     else if (!strcmp(key, "large_wg")) c->opt_large_wg = value == 256 ? 256 : (value == 1024 ? 1024 : 512);
@@ -1154,10 +1156,16 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         if (run < 1) run = 1;
         if (run > 64) run = 64;
         if (run > n_seg) run = n_seg;
+        // plenty of PSDs (>= two per CU) and whole-workgroup lines: one workgroup walks all segments of a PSD and
+        // finishes it itself -- no slabs, no second launch
+        const bool fused = sub == 1 && c->opt_lines_per_wg <= 0 && !c->opt_welch_two_pass && (uint64_t)n_psd >= 2ull * (uint64_t)c->n_cu;
+        if (fused) run = n_seg;
         const uint32_t wgs = (uint32_t)((n_seg + run * sub - 1) / (run * sub));
         const uint32_t n_slabs = wgs * sub;
-        st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)n_psd * n_slabs * nfft * sizeof(float));
-        if (st != SPEC_OK) return st;
+        if (!fused) {
+            st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)n_psd * n_slabs * nfft * sizeof(float));
+            if (st != SPEC_OK) return st;
+        }
         a.partial = c->scratch;
         float *d_out = psd_out;
         if (!out_on_device) {
@@ -1165,11 +1173,16 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
             if (st != SPEC_OK) return st;
             d_out = static_cast<float *>(c->stage_out);
         }
+        const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
+        a.final_out = fused ? d_out : nullptr;
+        a.norm = norm;
+        a.db = db;
         hipError_t e = launch_v2_welch(a, log2n, (uint32_t)run, wgs, c->stream);
         if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch launch: %s", hipGetErrorString(e));
-        const double norm = (scaling == SPEC_PSD_DENSITY ? 1.0 / (fs * s2) : 1.0 / (s1 * s1)) / (double)n_seg;
-        e = launch_welch_finalize(a.partial, 0, n_psd, n_slabs, nfft, norm, db, d_out, 0, c->stream);
-        if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch finalize launch: %s", hipGetErrorString(e));
+        if (!fused) {
+            e = launch_welch_finalize(a.partial, 0, n_psd, n_slabs, nfft, norm, db, d_out, 0, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch finalize launch: %s", hipGetErrorString(e));
+        }
         if (!out_on_device) {
             HIP_TRY(c, hipMemcpyAsync(psd_out, d_out, (size_t)n_psd * nfft * sizeof(float), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));

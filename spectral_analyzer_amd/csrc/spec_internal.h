@@ -36,6 +36,12 @@ struct WelchArgs {
     int kind, be;
     const void *tw, *win;
     void *partial;              // [n_psd][slabs][N] unshifted power sums (fp32; fp64 for launch_v3d_welch)
+    // launch_v2_welch with ONE workgroup and ONE sub-line per PSD (wgs_per_unit == 1, whole-workgroup lines): the
+    // kernel finishes the PSD itself -- sum * norm, fftshift, optional 10 log10 -- into final_out (float[n_psd][N])
+    // and no slab is written; nullptr: slabs + launch_welch_finalize
+    void *final_out = nullptr;
+    double norm = 0.0;
+    int db = 0;
 };
 
 int plan_lpw(int log2n);  // lines a workgroup transforms concurrently

@@ -335,6 +335,9 @@ struct V2Args {
     int be;                 // big-endian components
     const int32_t *sel;     // MODE 2: column of bin k (unshifted index) in the compact line, or -1
     uint32_t out_stride;    // MODE 2: floats per compact line
+    void *final_out;        // MODE 1, one sub-line per unit: the finished PSDs (float[n_units][N]) instead of slabs
+    double norm;            //         sum -> PSD factor (WelchArgs)
+    int db;                 //         10 log10(psd + 1e-20)
 };
 
 // MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums; MODE 2: spectrogram
@@ -497,9 +500,22 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
         for (uint32_t line = 0; line < iters; ++line) do_line(line, std::integral_constant<int, 0>{});
     }
     if constexpr (MODE == 1) {
+        constexpr float s2 = RW::SCALE * RW::SCALE;
+        if constexpr (PL::LPW == 1) {
+            if (a.final_out) {
+                // this workgroup has summed every segment of its PSD: finish it here, with welch_finalize_kernel's
+                // arithmetic for a single slab (fp32 sum -> double, * norm, fftshift, optional dB)
+                float *psd = static_cast<float *>(a.final_out) + (uint64_t)unit * N;
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const double v = (double)(acc[m] * s2) * a.norm;
+                    psd[(t + ((m + E / 2) & (E - 1)) * T)] = a.db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+                }
+                return;
+            }
+        }
         // one fp32 slab per sub-line (zeros for idle ones); welch_finalize_kernel sums them in order
         float *slab = static_cast<float *>(a.out) + ((uint64_t)blockIdx.x * PL::LPW + q) * N;
-        constexpr float s2 = RW::SCALE * RW::SCALE;
 #pragma unroll
         for (int m = 0; m < E; ++m) slab[t + m * T] = acc[m] * s2;
     }

@@ -207,6 +207,42 @@ def test_welch_batch_and_defaults(svc, oracle):
         svc.welch_psd(iq, 0, dt, fs, nfft=nfft, hop=hop, n_seg=10 ** 6)
 
 
+@pytest.mark.parametrize("datatype,nfft,hop,n_seg", [("cf32_le", 2048, 512, 9), ("ci16_le", 4096, 2048, 5),
+                                                      ("cf32_le", 16384, 4096, 3)])
+def test_welch_large_batch_finished_in_kernel(svc, oracle, datatype, nfft, hop, n_seg):
+    """>= two PSDs per CU with whole-workgroup lines: the workgroup that walked a PSD's segments finishes it (no
+    slabs, no second launch).  Same numbers as the two-launch form forced by "welch_two_pass" to fp32 summation
+    order, and the oracle's on sampled PSDs; linear and dB."""
+    import torch
+    n_psd, fs = 600, 2.5e6
+    bps = sa.bytes_per_sample(datatype)
+    per = (n_seg - 1) * hop + nfft
+    iq = svc.synth_iq(datatype, 21, 0, per * n_psd)
+    try:
+        res = {}
+        for two in (0, 1):
+            svc.set_option("welch_two_pass", two)
+            _, p = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, n_psd=n_psd, psd_stride_bytes=per * bps)
+            _, pdb = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, n_psd=n_psd,
+                                   psd_stride_bytes=per * bps, db=True)
+            torch.cuda.synchronize()
+            res[two] = (p.clone(), pdb.clone())
+    finally:
+        svc.set_option("welch_two_pass", 0)
+    p, pdb = res[0]
+    assert p.shape == (n_psd, nfft)
+    assert float(((p - res[1][0]).abs().amax(dim=1) / p.amax(dim=1)).max()) <= 2e-6
+    assert float((pdb - res[1][1]).abs().max()) <= 1e-3
+    host = iq.cpu().numpy()
+    for b in (0, 299, n_psd - 1):
+        _, ref = oracle.welch_psd(host, b * per * bps, datatype, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY, fs)
+        assert np.abs(p[b].cpu().numpy() - ref).max() <= 5e-6 * ref.max()
+        _, ref_db = oracle.welch_psd(host, b * per * bps, datatype, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY,
+                                     fs, db=True)
+        strong = ref >= 1e-6 * ref.max()
+        assert np.abs(pdb[b].cpu().numpy() - ref_db)[strong].max() <= 2e-3
+
+
 # ---- committed golden vectors --------------------------------------------------------------------
 def test_golden_fixtures_on_gpu(svc):
     files = sorted(f for f in os.listdir(GOLDEN) if f.startswith("wf_") and f.endswith(".npz"))
