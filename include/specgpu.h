@@ -125,7 +125,9 @@ void *spec_stream(const spec_ctx *ctx);
  *                     persistent launch for any number of lines and no fall-back (the call then waits for the
  *                     kernel and returns SPEC_EDEVICE if one of its bounded waits timed out)
  *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 3)
- *   "large_wg" = 256 | 512  threads per workgroup of the persistent launch (default 512: 16-bin = 128-byte output runs)
+ *   "large_wg" = 256 | 512  threads per workgroup of the persistent launch (default 512: one workgroup per CU, 16-bin =
+ *                     128-byte output runs; 256: two per CU, one column and one row workgroup on every CU -- measured
+ *                     slower, kept for tests)
  *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
  *   "render_fused" = 0 | 1   spec_waterfall_render stores only the bins the image samples (default 1; 0 = full
  *                     dB tile, then the colour kernel: the two forms give identical pixels)
