@@ -54,6 +54,7 @@ WORKLOADS = {
     "n65536f": dict(kind="spectro", datatype="cf32_le", nfft=65536, hop=32768, log2s=30, window=0, out="f32"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+GATHER_TIMEOUT_S = 240  # N > 1: the compute + gather phase is abandoned after this long (the headline is kept)
 FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 SEED = 0x5EC7A11A
 
@@ -198,45 +199,6 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(t[0].item()), float(t[1].item())
 
-    # ---- N > 1: the same step with the tiles gathered on rank 0, chunk sends overlapped with compute ----
-    gather = None
-    if dist is not None and not welch:
-        try:
-            chunks = max(1, args.gather_chunks)
-            comm = torch.cuda.Stream()
-            full = torch.empty((total_lines, nfft), dtype=out.dtype, device=out.device) if rank == 0 else None
-
-            def compute_rows(a, b, view):
-                svc.compute_waterfall(iq, (a - l0) * hop * bps, nfft, datatype, b - a, hop=hop, window=window,
-                                      out_fmt=out_fmt, out=view)
-
-            def gstep():
-                sd.sharded_waterfall_overlapped(compute_rows, total_lines, nfft, n_chunks=chunks, dst=0,
-                                                out=full if rank == 0 else out, comm_stream=comm)
-
-            gstep()
-            fence()
-            g0 = time.perf_counter()
-            for _ in range(max(1, args.gather_steps)):
-                gstep()
-            fence()
-            gsec = (time.perf_counter() - g0) / max(1, args.gather_steps)
-            t = torch.tensor([gsec], dtype=torch.float64, device=red_dev or iq.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gsec = float(t.item())
-            ok = None
-            if rank == 0:  # the root's own rows of the gathered tile are the lines the plain step produced
-                ok = bool(torch.equal(full[l0:l1], out))
-            peer_bytes = (total_lines - n_lines) * nfft * out.element_size()
-            gather = {"value": total_lines / gsec, "unit": "lines/s", "ms_per_step": gsec * 1e3, "chunks": chunks,
-                      "steps": max(1, args.gather_steps), "GBps_into_root": peer_bytes / gsec / 1e9,
-                      "root_rows_equal_plain_step": ok,
-                      "what": "compute + gather of every rank's tile on rank 0: %d chunk sends per rank on a second "
-                              "stream behind the chunk's kernels (dist.sharded_waterfall_overlapped)" % chunks}
-            del full
-        except Exception as e:  # the gather timing must never take the headline down with it
-            gather = {"error": repr(e)}
-
     # ---- outside the timed region: spot check against the oracle, CPU baseline ----
     checked = None
     cpu_baseline = None
@@ -288,6 +250,7 @@ def main() -> None:
         copy_gbps = 2.0 * out.numel() * out.element_size() / (float(np.median([a.elapsed_time(b) for a, b in cev])) * 1e-3) / 1e9
         del dst
 
+    res = None
     if rank == 0:
         value = total_lines * args.steps / elapsed
         traffic = None
@@ -339,6 +302,75 @@ def main() -> None:
             "cpu_baseline": cpu_baseline,
             "parity_spot_check": checked,
         }
+
+
+    # ---- N > 1: the same step with the tiles gathered on rank 0, chunk sends overlapped with compute.  LAST, and under
+    # a watchdog: whatever happens in here (a rank that cannot allocate, a transport that stalls), rank 0 still prints the
+    # headline line and every rank leaves.
+    gather = None
+    if dist is not None and not welch:
+        import threading
+
+        def bail():
+            if rank == 0:
+                res["gather"] = {"error": "gather phase abandoned after %d s" % GATHER_TIMEOUT_S}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        fence()
+        dog = threading.Timer(GATHER_TIMEOUT_S, bail)
+        dog.daemon = True
+        dog.start()
+        # every rank must take the same decision: a root that cannot hold the gathered tile would otherwise leave its
+        # peers waiting in their sends
+        full, comm, ready = None, None, 1.0
+        try:
+            comm = torch.cuda.Stream()
+            if rank == 0:
+                full = torch.empty((total_lines, nfft), dtype=out.dtype, device=out.device)
+        except Exception:
+            ready = 0.0
+        t = torch.tensor([ready], dtype=torch.float64, device=red_dev or iq.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if float(t.item()) < 1.0:
+            gather = {"error": "skipped: the root could not allocate the gathered tile (%d x %d %s)" % (total_lines, nfft, out.dtype)}
+        else:
+            try:
+                chunks = max(1, args.gather_chunks)
+
+                def compute_rows(a, b, view):
+                    svc.compute_waterfall(iq, (a - l0) * hop * bps, nfft, datatype, b - a, hop=hop, window=window,
+                                          out_fmt=out_fmt, out=view)
+
+                def gstep():
+                    sd.sharded_waterfall_overlapped(compute_rows, total_lines, nfft, n_chunks=chunks, dst=0,
+                                                    out=full if rank == 0 else out, comm_stream=comm)
+
+                gstep()
+                fence()
+                g0 = time.perf_counter()
+                for _ in range(max(1, args.gather_steps)):
+                    gstep()
+                fence()
+                gsec = (time.perf_counter() - g0) / max(1, args.gather_steps)
+                t = torch.tensor([gsec], dtype=torch.float64, device=red_dev or iq.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                gsec = float(t.item())
+                ok = None
+                if rank == 0:  # the root's own rows of the gathered tile are the lines the plain step produced
+                    ok = bool(torch.equal(full[l0:l1], out))
+                peer_bytes = (total_lines - n_lines) * nfft * out.element_size()
+                gather = {"value": total_lines / gsec, "unit": "lines/s", "ms_per_step": gsec * 1e3, "chunks": chunks,
+                          "steps": max(1, args.gather_steps), "GBps_into_root": peer_bytes / gsec / 1e9,
+                          "root_rows_equal_plain_step": ok,
+                          "what": "compute + gather of every rank's tile on rank 0: %d chunk sends per rank on a second "
+                                  "stream behind the chunk's kernels (dist.sharded_waterfall_overlapped)" % chunks}
+            except Exception as e:  # the gather timing must never take the headline down with it
+                gather = {"error": repr(e)}
+        dog.cancel()
+        del full
+
+    if rank == 0:
         if gather is not None:
             res["gather"] = gather
         print(json.dumps(res), flush=True)
