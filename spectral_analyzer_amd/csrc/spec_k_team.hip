@@ -737,7 +737,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             auto emit = [&](auto fmt_tag) {  // one format per call: the branch on the format is outside the bins
                 constexpr int FMT = decltype(fmt_tag)::value;
                 using TO = std::conditional_t<(FMT >= OUT_DB20_F64), double, float>;
-#if defined(SPEC_TEAM_SINGLE_STORES) || defined(SPEC_ABL_TEAM_NOSTORE)
+#if defined(SPEC_ABL_TEAM_NOSTORE)
                 between(std::integral_constant<int, 4>{});
 #pragma unroll
                 for (int m = 0; m < TE; ++m) {
@@ -745,11 +745,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     emit_bin<R, FMT>(a.out, base + ((k + N / 2) & (N - 1)), v[m], s_dbt);  // SS:78
                 }
 #else
-                // A thread holds bin k1 = r0 + q0 of eight rows k2; its neighbour (lane ^ 1) holds k1 ^ 1 of the same
-                // rows.  Even lanes store {k1, k1 + 1} of the rows m = 0, 2, 4, 6, odd lanes {k1 - 1, k1} of the rows
-                // m = 1, 3, 5, 7: TE / 2 stores of two bins each instead of TE stores of one (the row side's output
-                // stores were what a line waited for longest).
-                TO d[TE], o[TE];
+                TO d[TE];
 #ifndef SPEC_ABL_TEAM_NOEPI
                 if constexpr (FMT == OUT_DB20_F64 && sizeof(R) == 8) {
                     db20_tab_n<TE>(v, s_dbt, d);
@@ -759,10 +755,24 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #pragma unroll
                     for (int m = 0; m < TE; ++m) d[m] = (TO)bin_value<R, FMT>(v[m], s_dbt);
                 }
+                TO *out = static_cast<TO *>(a.out);
+#ifdef SPEC_TEAM_SINGLE_STORES
+                // one store per bin: a thread holds bin k1 = r0 + q0 of eight rows k2 (the C lanes of a row k2 write one run)
+                asm volatile("" ::: "memory");
+                between(std::integral_constant<int, 4>{});
+#pragma unroll
+                for (int m = 0; m < TE; ++m) {
+                    const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + m * PB::T);
+                    __builtin_nontemporal_store(d[m], out + base + ((k + N / 2) & (N - 1)));  // SS:78
+                }
+#else
+                // A thread holds bin k1 = r0 + q0 of eight rows k2; its neighbour (lane ^ 1) holds k1 ^ 1 of the same
+                // rows.  Even lanes store {k1, k1 + 1} of the rows m = 0, 2, 4, 6, odd lanes {k1 - 1, k1} of the rows
+                // m = 1, 3, 5, 7: TE / 2 stores of two bins each instead of TE stores of one.
+                TO o[TE];
 #pragma unroll
                 for (int m = 0; m < TE; ++m) o[m] = lane_swap1(d[m]);
                 const bool odd = (q0 & 1) != 0;
-                TO *out = static_cast<TO *>(a.out);
                 asm volatile("" ::: "memory");
                 between(std::integral_constant<int, 4>{});
 #pragma unroll
@@ -772,6 +782,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     const uint32_t k = (r0 + ((uint32_t)q0 & ~1u)) + (uint32_t)N1 * k2;  // the even bin of the pair
                     st_pair<TO>(out + base + ((k + N / 2) & (N - 1)), odd ? o[mo] : d[me], odd ? d[mo] : o[me]);  // SS:78
                 }
+#endif
 #endif
             };
             asm volatile("" ::: "memory");
