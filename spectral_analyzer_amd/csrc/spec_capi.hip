@@ -1158,7 +1158,9 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         if (run > n_seg) run = n_seg;
         // plenty of PSDs (>= two per CU) and whole-workgroup lines: one workgroup walks all segments of a PSD and
         // finishes it itself -- no slabs, no second launch
-        const bool fused = sub == 1 && c->opt_lines_per_wg <= 0 && !c->opt_welch_two_pass && (uint64_t)n_psd >= 2ull * (uint64_t)c->n_cu;
+        // (a workgroup addresses its span through one buffer descriptor: 32-bit byte range)
+        const bool fused = sub == 1 && c->opt_lines_per_wg <= 0 && !c->opt_welch_two_pass && (uint64_t)n_psd >= 2ull * (uint64_t)c->n_cu &&
+                           ((uint64_t)n_seg - 1) * hop * bps + (uint64_t)nfft * bps < (1ull << 31);
         if (fused) run = n_seg;
         const uint32_t wgs = (uint32_t)((n_seg + run * sub - 1) / (run * sub));
         const uint32_t n_slabs = wgs * sub;
