@@ -191,8 +191,8 @@ template <typename R, int L, int WG> __device__ __forceinline__ void xload(cx<R>
 // register destination, nothing for the compiler to copy): every wave lands its loads in a private 1 KiB-per-
 // instruction strip of LDS (lane l at byte 16 l), waits with vm_wait<N> -- "all but the N youngest vector-memory
 // instructions of this wave are done", N a LOWER bound of the instructions issued since -- and reads its own
-// lanes back with ds_read_b128.  The waits carry a "memory" clobber: no LDS read moves above them.  Only the
-// fp64 kernels are pipelined this way (LDS-DMA moves 4 or 16 bytes per lane; a cx<float> is 8).
+// lanes back with ds_read_b128.  The waits carry a "memory" clobber: no LDS read moves above them.  LDS-DMA moves
+// 4 or 16 bytes per lane: a cx<double> each, or two neighbouring cx<float> of one row (dma_coords in the kernel).
 #ifdef SPEC_TEAM_STRICT_WAITS  // debugging aid: every counted wait becomes vmcnt(0)
 #define VM_N(N) 0
 #else
@@ -353,17 +353,18 @@ template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *ou
 #endif
 }
 
-// Dynamic LDS of one workgroup.  fp64 (pipelined loads): 256 bytes for the polled counter word, then the landing
-// strips -- WG / 64 waves x TE instructions x 1 KiB -- FIRST, so that every strip's base address fits the 16
-// bits of M0 that are certain to carry it; then line buffers + sub-transform table (MAIN, in cx<R> elements).
+// Dynamic LDS of one workgroup.  Pipelined loads: 256 bytes for the polled counter word, then the landing
+// strips -- WG / 64 waves x TE x 64 elements (one 1 KiB instruction lands 64 cx<double> or 128 cx<float>) -- FIRST,
+// so that every strip's base address fits the 16 bits of M0 that are certain to carry it; then line buffers +
+// sub-transform table (MAIN, in cx<R> elements).
 // DENSE: two workgroups per CU (four waves per SIMD, 128 registers each) that hide latency by occupancy: no
 // landing strips, the plain forms of both sides.
 template <typename R, int L1, int L2, int WG, bool DENSE> struct TeamLds {
     static constexpr size_t A = (size_t)TP<L1, WG>::C * TP<L1, WG>::SL + TP<L1, WG>::M;
     static constexpr size_t B = (size_t)TP<L2, WG>::C * TP<L2, WG>::SL + TP<L2, WG>::M;
     static constexpr size_t MAIN = A > B ? A : B;
-    static constexpr bool PIPE = sizeof(R) == 8 && !DENSE;
-    static constexpr size_t LAND_BYTES = PIPE ? 256 + (size_t)(WG / 64) * TE * 1024 : 0;
+    static constexpr bool PIPE = !DENSE;
+    static constexpr size_t LAND_BYTES = PIPE ? 256 + (size_t)(WG / 64) * TE * 64 * sizeof(cx<R>) : 0;
     static constexpr size_t DBT_OFF = LAND_BYTES + MAIN * sizeof(cx<R>);  // table of the fp64 dB epilogue (spec_fft.h)
     static constexpr size_t BYTES = DBT_OFF + DB20_TAB_DOUBLES * sizeof(double);
     // the last strip starts at LAND_BYTES - 1024 behind the kernel's static __shared__ words (< 768 bytes)
@@ -481,10 +482,23 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     uint32_t *ring = sync + TS_RING + team * (TEAM_RING_MAX * 32);  // slot s: doneA at 32 s, doneB at 32 s + 16
     const cx<double> *__restrict__ twn = static_cast<const cx<double> *>(a.twn);
     if (my_lines == 0) return;
-    // landing strips of the pipelined loads (fp64): this wave's strip m at land_addr + 1024 m, own lane at [64 m + lane]
+    // landing strips of the pipelined loads: element m of this wave's lane l at land[64 m + l].  One LDS-DMA
+    // instruction moves 16 bytes per lane = EPL elements: for cx<double> the lane's own element m = j; for cx<float>
+    // two neighbouring columns of ONE row, and the 64 lanes of instruction j cover the rows m = 2 j and 2 j + 1 of the
+    // wave's threads in exactly the [m][lane] order above (dma_coords below), so that only the requests differ
+    // between the two precisions, not what is read back.
     const uint32_t wave = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63;
+    constexpr int EPL = 16 / (int)sizeof(cx<R>);  // elements per lane and LDS-DMA instruction
+    constexpr int NI = TE / EPL;                   // instructions per tile and wave, 1 KiB of strip each
     uint32_t *pland = reinterpret_cast<uint32_t *>(smem);
-    cx<R> *land = reinterpret_cast<cx<R> *>(smem + 256 + (size_t)wave * TE * 1024);
+    cx<R> *land = reinterpret_cast<cx<R> *>(smem + 256 + (size_t)wave * TE * 64 * sizeof(cx<R>));
+    // which (row within the tile's thread grid, column, m offset) a lane REQUESTS for a tile C columns wide
+    struct DmaCoords { uint32_t t, q, mm; };
+    auto dma_coords = [&](uint32_t C) -> DmaCoords {
+        const uint32_t half = C / EPL, s = lane / half;         // EPL == 1: half = C, s = lane / C
+        const uint32_t per_wave = 64u / C;                       // thread rows t of one wave
+        return DmaCoords{wave * per_wave + s % per_wave, EPL * (lane % half), s / per_wave};
+    };
     const uint32_t land_addr = __builtin_amdgcn_readfirstlane(lds_addr(land));
     const uint32_t pland_addr = __builtin_amdgcn_readfirstlane(lds_addr(pland));
     (void)land_addr; (void)pland_addr; (void)lane;
@@ -530,13 +544,15 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 // half: the lower half of line i + 1 is the upper half of line i) land in the strips, requested one
                 // whole line earlier and issued BEHIND line i - 1's stores, so that the counted wait for those stores
                 // leaves them in flight.  Per line: [poll slot of line i + 1] [stores of line i] [loads of line i + 2].
-                constexpr int NLD = HALF ? NEWH : TE;  // LOWER bound of the loads issued behind a line's stores
+                constexpr int NLD = (HALF ? NEWH : TE) / EPL;  // LOWER bound of the loads issued behind a line's stores
+                const DmaCoords dc = dma_coords(PA::C);
                 auto issue = [&](uint32_t line, auto first_tag) {
                     constexpr int FIRST = decltype(first_tag)::value;
+                    static_assert(FIRST % EPL == 0, "whole instructions");
                     const uint8_t *src = a.iq + (uint64_t)line * a.hop * sizeof(cx<R>);
 #pragma unroll
-                    for (int m = FIRST; m < TE; ++m)
-                        glds16<0>(src + (uint64_t)((uint32_t)(t0 + m * PA::T) * N2 + c0 + q0) * sizeof(cx<R>), land_addr + 1024u * m);
+                    for (int j = FIRST / EPL; j < NI; ++j)
+                        glds16<0>(src + (uint64_t)((dc.t + (EPL * j + dc.mm) * PA::T) * N2 + c0 + dc.q) * sizeof(cx<R>), land_addr + 1024u * j);
                 };
                 // at the start of a block of lines all eight rows are requested (the counted wait then also waits for
                 // the first four of them, once per block)
@@ -799,15 +815,17 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         };
         auto ready = [&](uint32_t j, uint32_t w) { return j < my_lines && (int32_t)(w - NT * (j / a.ring + 1)) >= 0; };
         if constexpr (LD::PIPE) {
-            // ---- pipelined form (fp64) --------------------------------------------------------------------------------
+            // ---- pipelined form -----------------------------------------------------------------------------------------
             // Per line: [tile of line i + 1 into the strips, if the column side has it (poll taken one line earlier)]
             // [poll for line i + 2] [the 8 output stores of line i].  The tile is read at the top of the next
             // iteration behind vm_wait<8>: the loads and the poll are older than the stores, the stores stay in flight.
+            const DmaCoords dc = dma_coords(PB::C);
             auto issue_part = [&](uint32_t i, auto from_tag, auto to_tag) {
-                const cx<R> *src = slots + (uint64_t)(i % a.ring) * N + r0 + q0;
+                static_assert(decltype(from_tag)::value % EPL == 0 && decltype(to_tag)::value % EPL == 0, "whole instructions");
+                const cx<R> *src = slots + (uint64_t)(i % a.ring) * N + r0 + dc.q;
 #pragma unroll
-                for (int m = decltype(from_tag)::value; m < decltype(to_tag)::value; ++m)
-                    glds16<1>(src + (uint64_t)(t0 + m * PB::T) * N1, land_addr + 1024u * m);  // [n2][k1]
+                for (int j = decltype(from_tag)::value / EPL; j < decltype(to_tag)::value / EPL; ++j)
+                    glds16<1>(src + (uint64_t)(dc.t + (EPL * j + dc.mm) * PB::T) * N1, land_addr + 1024u * j);  // [n2][k1]
             };
             auto issue = [&](uint32_t i) { issue_part(i, std::integral_constant<int, 0>{}, std::integral_constant<int, TE>{}); };
             auto issue_poll = [&](uint32_t j) {  // doneA of line j's slot (lane 0)

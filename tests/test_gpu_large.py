@@ -33,6 +33,8 @@ CASES = [  # datatype, nfft, hop, n_lines, window, fp64 output
     ("ci16_le", 16384, 4096, 33, sa.WIN_HANN, True),      # fp64 pipeline asked for by the output format
     ("cf32_le", 65536, 32768, 19, sa.WIN_RECT, False),    # fp32 members
     ("cf32_le", 32768, 16384, 70, sa.WIN_RECT, False),
+    ("cf32_le", 32768, 12345, 9, sa.WIN_RECT, False),     # odd hop: 16-byte requests at 8-byte alignment
+    ("cf32_le", 65536, 65536, 5, sa.WIN_HANN, False),     # window: plain column side, pipelined row side
     ("ci16_le", 65536, 65536, 4, sa.WIN_RECT, False),
     ("cu8", 32768, 10000, 9, sa.WIN_HANN, False),
 ]
