@@ -7,9 +7,10 @@
 
 A "step" is one pass of the hot path (IQ bytes resident in HBM -> results in HBM) over the rank's
 shard of the synthetic recording.  Workloads (BASELINE.json configs):
-  cfg2  4096-pt FFT, 50 % overlap, cf32, 2^30 samples (524 287 lines) -- the metric's config, default at N = 1
-  cfg3  4096-pt, ci16 (on-GPU int16 -> float), 2^30 samples per GPU = the per-GPU share of the 8 G-sample
-        recording -- default at N > 1, with the tile gather timed beside the compute-only figure
+  cfg2  4096-pt FFT, 50 % overlap, cf32, 2^30 samples per GPU (524 287 lines) -- the metric's config and the default
+        at EVERY N, so that the per-N values of one scaling series are values of one workload (weak scaling)
+  cfg3  4096-pt, ci16 (on-GPU int16 -> float), 2^30 samples per GPU = the per-GPU share of BASELINE's 8 G-sample,
+        8-GPU recording (--workload cfg3); at N > 1 either one has the tile gather timed beside the compute-only figure
   cfg4  Welch PSD, 16384-pt, Hann, 75 % overlap, 256 segments per PSD, cf32; 1024 independent PSDs per step
         (one annotation each); a "line" is one segment; VALU-bound, so the roofline is the fp32 vector peak
   cfg5  65536-pt FFT, cf64 -> f64 (the whole pipeline in fp64), 2^30 samples per GPU (32 767 lines)
@@ -92,7 +93,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)  # the clock needs ~10 launches to settle
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: cfg2 on one GPU, cfg3 (the sharded configuration) on several")
+                    help="default: cfg2 (the metric's configuration) at every N; cfg3 = the per-GPU share of BASELINE's 8-GPU recording")
     ap.add_argument("--log2-samples", type=int, default=None, help="override samples per GPU (debug)")
     ap.add_argument("--n-psd", type=int, default=None, help="cfg4: PSDs per GPU and step (default 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,7 +111,7 @@ def main() -> None:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
     if args.workload is None:
-        args.workload = "cfg2" if world == 1 else "cfg3"
+        args.workload = "cfg2"
     # SPEC_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a ONE-GPU box -- every rank on device 0,
     # gloo instead of RCCL (which refuses two ranks on one device).  Never used by the driver.
     rehearse = os.environ.get("SPEC_BENCH_REHEARSE") == "1"
