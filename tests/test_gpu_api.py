@@ -207,9 +207,10 @@ def test_welch_batch_and_defaults(svc, oracle):
         svc.welch_psd(iq, 0, dt, fs, nfft=nfft, hop=hop, n_seg=10 ** 6)
 
 
-@pytest.mark.parametrize("datatype,nfft,hop,n_seg", [("cf32_le", 2048, 512, 9), ("ci16_le", 4096, 2048, 5),
-                                                      ("cf32_le", 16384, 4096, 3)])
-def test_welch_large_batch_finished_in_kernel(svc, oracle, datatype, nfft, hop, n_seg):
+@pytest.mark.parametrize("datatype,nfft,hop,n_seg,window,scaling", [
+    ("cf32_le", 2048, 512, 9, sa.WIN_HANN, sa.PSD_DENSITY), ("ci16_le", 4096, 2048, 5, sa.WIN_HANN, sa.PSD_DENSITY),
+    ("cf32_le", 16384, 4096, 3, sa.WIN_HANN, sa.PSD_DENSITY), ("cu8", 2048, 2048, 4, sa.WIN_RECT, sa.PSD_SPECTRUM)])
+def test_welch_large_batch_finished_in_kernel(svc, oracle, datatype, nfft, hop, n_seg, window, scaling):
     """>= two PSDs per CU with whole-workgroup lines: the workgroup that walked a PSD's segments finishes it (no
     slabs, no second launch).  Same numbers as the two-launch form forced by "welch_two_pass" to fp32 summation
     order, and the oracle's on sampled PSDs; linear and dB."""
@@ -222,9 +223,10 @@ def test_welch_large_batch_finished_in_kernel(svc, oracle, datatype, nfft, hop, 
         res = {}
         for two in (0, 1):
             svc.set_option("welch_two_pass", two)
-            _, p = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, n_psd=n_psd, psd_stride_bytes=per * bps)
-            _, pdb = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, n_psd=n_psd,
-                                   psd_stride_bytes=per * bps, db=True)
+            _, p = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=window, scaling=scaling, n_psd=n_psd,
+                               psd_stride_bytes=per * bps)
+            _, pdb = svc.welch_psd(iq, 0, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=window, scaling=scaling,
+                                   n_psd=n_psd, psd_stride_bytes=per * bps, db=True)
             torch.cuda.synchronize()
             res[two] = (p.clone(), pdb.clone())
     finally:
@@ -235,9 +237,9 @@ def test_welch_large_batch_finished_in_kernel(svc, oracle, datatype, nfft, hop, 
     assert float((pdb - res[1][1]).abs().max()) <= 1e-3
     host = iq.cpu().numpy()
     for b in (0, 299, n_psd - 1):
-        _, ref = oracle.welch_psd(host, b * per * bps, datatype, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY, fs)
+        _, ref = oracle.welch_psd(host, b * per * bps, datatype, nfft, hop, n_seg, window, scaling, fs)
         assert np.abs(p[b].cpu().numpy() - ref).max() <= 5e-6 * ref.max()
-        _, ref_db = oracle.welch_psd(host, b * per * bps, datatype, nfft, hop, n_seg, oracle.WIN_HANN, oracle.PSD_DENSITY,
+        _, ref_db = oracle.welch_psd(host, b * per * bps, datatype, nfft, hop, n_seg, window, scaling,
                                      fs, db=True)
         strong = ref >= 1e-6 * ref.max()
         assert np.abs(pdb[b].cpu().numpy() - ref_db)[strong].max() <= 2e-3
