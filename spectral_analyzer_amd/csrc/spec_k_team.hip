@@ -867,9 +867,6 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #else
                 const bool ahead = s_next != 0;
 #endif
-#ifdef SPEC_TEAM_EARLY_POLL
-                issue_poll(i + 2);
-#endif
                 rest_of_line(v, line_of(i), [&](auto stage) {  // every request is older than the line's output stores
                     constexpr int ST = decltype(stage)::value, Q = TE / 4;
                     if constexpr (ST < 4) {
@@ -877,9 +874,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     } else {
                         // has the column side stored line i + 2?  Asked as late as possible: the answer is read at the
                         // top of the next line, and a "not yet" costs that line a blocking wait and an exposed tile read
-#ifndef SPEC_TEAM_EARLY_POLL
                         issue_poll(i + 2);
-#endif
                     }
                 });
                 if (!ahead && i + 1 < my_lines) {  // the column side is not ahead: wait for it here
