@@ -761,44 +761,55 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     emit_bin<R, FMT>(a.out, base + ((k + N / 2) & (N - 1)), v[m], s_dbt);  // SS:78
                 }
 #else
-                TO d[TE];
-#ifndef SPEC_ABL_TEAM_NOEPI
-                if constexpr (FMT == OUT_DB20_F64 && sizeof(R) == 8) {
-                    db20_tab_n<TE>(v, s_dbt, d);
-                } else
-#endif
-                {
-#pragma unroll
-                    for (int m = 0; m < TE; ++m) d[m] = (TO)bin_value<R, FMT>(v[m], s_dbt);
-                }
                 TO *out = static_cast<TO *>(a.out);
-#ifdef SPEC_TEAM_SINGLE_STORES
-                // one store per bin: a thread holds bin k1 = r0 + q0 of eight rows k2 (the C lanes of a row k2 write one run)
-                asm volatile("" ::: "memory");
-                between(std::integral_constant<int, 4>{});
-#pragma unroll
-                for (int m = 0; m < TE; ++m) {
-                    const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + m * PB::T);
-                    __builtin_nontemporal_store(d[m], out + base + ((k + N / 2) & (N - 1)));  // SS:78
-                }
-#else
-                // A thread holds bin k1 = r0 + q0 of eight rows k2; its neighbour (lane ^ 1) holds k1 ^ 1 of the same
-                // rows.  Even lanes store {k1, k1 + 1} of the rows m = 0, 2, 4, 6, odd lanes {k1 - 1, k1} of the rows
-                // m = 1, 3, 5, 7: TE / 2 stores of two bins each instead of TE stores of one.
-                TO o[TE];
-#pragma unroll
-                for (int m = 0; m < TE; ++m) o[m] = lane_swap1(d[m]);
+                // the epilogue in two halves: the first half's stores go out while the second half is computed (the
+                // ring poll in front of the first store: every store of the line stays younger than it); 1-2 % over
+                // all eight bins first
+                constexpr int NH = 2;
+                constexpr int HB = TE / NH;  // bins per part
                 const bool odd = (q0 & 1) != 0;
-                asm volatile("" ::: "memory");
-                between(std::integral_constant<int, 4>{});
 #pragma unroll
-                for (int pr = 0; pr < TE / 2; ++pr) {
-                    const int me = 2 * pr, mo = 2 * pr + 1;
-                    const uint32_t k2 = (uint32_t)t0 + (uint32_t)(odd ? mo : me) * PB::T;
-                    const uint32_t k = (r0 + ((uint32_t)q0 & ~1u)) + (uint32_t)N1 * k2;  // the even bin of the pair
-                    st_pair<TO>(out + base + ((k + N / 2) & (N - 1)), odd ? o[mo] : d[me], odd ? d[mo] : o[me]);  // SS:78
-                }
+                for (int h = 0; h < NH; ++h) {
+                    TO d[HB];
+                    cx<R> z[HB];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) z[m] = v[h * HB + m];
+#ifndef SPEC_ABL_TEAM_NOEPI
+                    if constexpr (FMT == OUT_DB20_F64 && sizeof(R) == 8) {
+                        db20_tab_n<HB>(z, s_dbt, d);
+                    } else
 #endif
+                    {
+#pragma unroll
+                        for (int m = 0; m < HB; ++m) d[m] = (TO)bin_value<R, FMT>(z[m], s_dbt);
+                    }
+#ifdef SPEC_TEAM_SINGLE_STORES
+                    // one store per bin: a thread holds bin k1 = r0 + q0 of eight rows k2 (the C lanes of a row k2 write one run)
+                    asm volatile("" ::: "memory");
+                    if (h == 0) between(std::integral_constant<int, 4>{});
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) {
+                        const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + (h * HB + m) * PB::T);
+                        __builtin_nontemporal_store(d[m], out + base + ((k + N / 2) & (N - 1)));  // SS:78
+                    }
+#else
+                    // A thread holds bin k1 = r0 + q0 of eight rows k2; its neighbour (lane ^ 1) holds k1 ^ 1 of the same
+                    // rows.  Even lanes store {k1, k1 + 1} of the rows m = 0, 2, 4, 6, odd lanes {k1 - 1, k1} of the rows
+                    // m = 1, 3, 5, 7: TE / 2 stores of two bins each instead of TE stores of one.
+                    TO o[HB];
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) o[m] = lane_swap1(d[m]);
+                    asm volatile("" ::: "memory");
+                    if (h == 0) between(std::integral_constant<int, 4>{});
+#pragma unroll
+                    for (int pr = 0; pr < HB / 2; ++pr) {
+                        const int me = 2 * pr, mo = 2 * pr + 1;
+                        const uint32_t k2 = (uint32_t)t0 + (uint32_t)(h * HB + (odd ? mo : me)) * PB::T;
+                        const uint32_t k = (r0 + ((uint32_t)q0 & ~1u)) + (uint32_t)N1 * k2;  // the even bin of the pair
+                        st_pair<TO>(out + base + ((k + N / 2) & (N - 1)), odd ? o[mo] : d[me], odd ? d[mo] : o[me]);  // SS:78
+                    }
+#endif
+                }
 #endif
             };
             asm volatile("" ::: "memory");
