@@ -722,33 +722,8 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         PassTw<R, L2, WG> twr;
         constexpr bool TWREG = !DENSE;
         if constexpr (TWREG) twr.load(t0, tab);
-        // the rest of one line behind its first pass and exchange
-        // `between(stage)`, stage 0 .. 3: the caller's requests for the next tile, a quarter of them in front of each
-        // stretch of arithmetic instead of all at once (eight 1 KiB requests per wave keep the texture addresser busy
-        // for ~130 cycles per wave, ~1000 per workgroup, during which nobody computed); stage 4: between the
-        // epilogue's arithmetic and its stores (the caller's poll of the ring: as late as the order of the waits allows)
-        auto rest_of_line = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
-            between(std::integral_constant<int, 0>{});
-            PROF_PH(2);  // hand-back, first requests for the next tile
-            xload<R, L2, WG>(v, t0, line_lds);
-            __syncthreads();
-            PROF_PH(3);
-            between(std::integral_constant<int, 1>{});
-#ifndef SPEC_ABL_TEAM_NOFFT
-            if constexpr (TWREG) twr.pass1(v);
-            else pass1<R, L2, WG>(v, t0, tab);
-#endif
-            between(std::integral_constant<int, 2>{});
-            xstore1<R>(v, t0, line_lds);
-            __syncthreads();
-            PROF_PH(4);
-            between(std::integral_constant<int, 3>{});
-            xload<R, L2, WG>(v, t0, line_lds);
-#ifndef SPEC_ABL_TEAM_NOFFT
-            if constexpr (TWREG) twr.pass2(v);
-            else pass2<R, L2, WG>(v, t0, tab);
-#endif
-            PROF_PH(5);
+        // the epilogue of one line (SS:76-82) and its stores; between(4) sits in front of the first store
+        auto epilogue = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
             const uint64_t base = (uint64_t)line * N;
             auto emit = [&](auto fmt_tag) {  // one format per call: the branch on the format is outside the bins
                 constexpr int FMT = decltype(fmt_tag)::value;
@@ -820,10 +795,87 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             default: emit(std::integral_constant<int, OUT_POW_F64>{}); break;
             }
             asm volatile("" ::: "memory");
+        };
+        // The rest of one line behind its first pass and exchange.
+        // `between(stage)`: the caller's requests for the next tile, a part of them in front of each stretch of arithmetic
+        // instead of all at once (eight 1 KiB requests per wave keep the texture addresser busy for ~130 cycles per wave,
+        // ~1000 per workgroup, during which nobody computed); stage 4: between the epilogue's arithmetic and its stores
+        // (the caller's poll of the ring: as late as the order of the counted waits allows).
+        // Plain form: both exchanges in the line buffers, four barriers per line, stages 0 .. 3.
+        auto rest_of_line = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
+            between(std::integral_constant<int, 0>{});
+            PROF_PH(2);  // hand-back, first requests for the next tile
+            xload<R, L2, WG>(v, t0, line_lds);
+            __syncthreads();
+            PROF_PH(3);
+            between(std::integral_constant<int, 1>{});
+#ifndef SPEC_ABL_TEAM_NOFFT
+            if constexpr (TWREG) twr.pass1(v);
+            else pass1<R, L2, WG>(v, t0, tab);
+#endif
+            between(std::integral_constant<int, 2>{});
+            xstore1<R>(v, t0, line_lds);
+            __syncthreads();
+            PROF_PH(4);
+            between(std::integral_constant<int, 3>{});
+            xload<R, L2, WG>(v, t0, line_lds);
+#ifndef SPEC_ABL_TEAM_NOFFT
+            if constexpr (TWREG) twr.pass2(v);
+            else pass2<R, L2, WG>(v, t0, tab);
+#endif
+            PROF_PH(5);
+            epilogue(v, line, between);
             PROF_PH(6);
             __syncthreads();  // the line buffers are rewritten by the next line's first exchange
             PROF_PH(7);
         };
+        // Pipelined form: the FIRST exchange lives in the landing strips.  After pass 0 the threads of wave w hold,
+        // of every row q of the tile, the G = 512 / C consecutive elements [w G, (w + 1) G): C rows x G elements =
+        // 512 elements, exactly the wave's own strip -- so every wave WRITES only its own strip (which it has just
+        // read: no barrier in front), and after the one barrier everybody reads across the strips.  The second
+        // exchange keeps the line buffers.  Two barriers per line instead of four (none between a line's last LDS read
+        // and the next line's first LDS write: those are different buffers now); the price is that the next tile may
+        // be requested only behind the second barrier (everybody has read the strips), stages 3, 5, 6.
+        // Element g of row q sits at [q G + (g ^ (q & 15))]: 16 lanes of one row-major access hit 16 different
+        // 16-byte slots on the write (g fixed per instruction) and on the read side alike.
+        constexpr uint32_t SXG = 8u * 64u / PB::C, SXR = SXG / PB::T;
+        static_assert(SXG == PB::T * SXR && (SXR == 1 || SXR == 2) && SXG >= 16, "strip exchange: a row's share per wave");
+        const uint32_t sx_qs = (uint32_t)q0 & 15u;
+        cx<R> *sx_wr = land + (size_t)q0 * SXG;                                       // own strip, row q0
+        const uint32_t sx_b8 = (8u * ((uint32_t)t0 % (64u / PB::C))) ^ sx_qs;          // (8 tl + r) ^ qs == sx_b8 ^ r
+        const cx<R> *sx_rd = reinterpret_cast<const cx<R> *>(smem + 256) + (size_t)q0 * SXG + ((uint32_t)t0 ^ sx_qs);
+        auto xstore0s = [&](const cx<R> (&v)[TE]) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sx_wr[sx_b8 ^ (uint32_t)r] = v[r];
+        };
+        auto xload0s = [&](cx<R> (&v)[TE]) {  // element t0 + m T of row q0: written by wave m / SXR
+#pragma unroll
+            for (int m = 0; m < TE; ++m) v[m] = sx_rd[(m / (int)SXR) * (TE * 64) + (int)PB::T * (m % (int)SXR)];
+        };
+        auto rest_of_line_sx = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
+            PROF_PH(2);
+            xload0s(v);
+            PROF_PH(3);
+#ifndef SPEC_ABL_TEAM_NOFFT
+            if constexpr (TWREG) twr.pass1(v);
+            else pass1<R, L2, WG>(v, t0, tab);
+#endif
+            xstore1<R>(v, t0, line_lds);
+            __syncthreads();  // everybody has read the strips and written the line buffers
+            PROF_PH(4);
+            between(std::integral_constant<int, 3>{});
+            xload<R, L2, WG>(v, t0, line_lds);
+            between(std::integral_constant<int, 5>{});
+#ifndef SPEC_ABL_TEAM_NOFFT
+            if constexpr (TWREG) twr.pass2(v);
+            else pass2<R, L2, WG>(v, t0, tab);
+#endif
+            between(std::integral_constant<int, 6>{});
+            PROF_PH(5);
+            epilogue(v, line, between);
+            PROF_PH(6);
+        };
+        (void)xstore0s; (void)rest_of_line_sx; (void)rest_of_line;
         auto ready = [&](uint32_t j, uint32_t w) { return j < my_lines && (int32_t)(w - NT * (j / a.ring + 1)) >= 0; };
         if constexpr (LD::PIPE) {
             // ---- pipelined form -----------------------------------------------------------------------------------------
@@ -866,7 +918,11 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #ifndef SPEC_ABL_TEAM_NOFFT
                 dft8(v);
 #endif
+#ifdef SPEC_TEAM_NO_STRIPX
                 xstore0<R>(v, t0, line_lds);
+#else
+                xstore0s(v);  // into this wave's own strip (just read): no barrier in front
+#endif
                 if (tid == 0) s_next = ready(i + 1, pland[0]);
                 PROF_PH(0);
                 __syncthreads();
@@ -878,16 +934,31 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #else
                 const bool ahead = s_next != 0;
 #endif
-                rest_of_line(v, line_of(i), [&](auto stage) {  // every request is older than the line's output stores
+                auto requests = [&](auto stage) {  // every request is older than the line's output stores
                     constexpr int ST = decltype(stage)::value, Q = TE / 4;
-                    if constexpr (ST < 4) {
-                        if (ahead) issue_part(i + 1, std::integral_constant<int, ST * Q>{}, std::integral_constant<int, ST * Q + Q>{});
-                    } else {
+                    if constexpr (ST == 4) {
                         // has the column side stored line i + 2?  Asked as late as possible: the answer is read at the
                         // top of the next line, and a "not yet" costs that line a blocking wait and an exposed tile read
                         issue_poll(i + 2);
+                    } else if constexpr (ST < 4) {
+#ifdef SPEC_TEAM_NO_STRIPX
+                        if (ahead) issue_part(i + 1, std::integral_constant<int, ST * Q>{}, std::integral_constant<int, ST * Q + Q>{});
+#else
+                        // strip exchange: nothing may land before everybody has read the strips (stage 3 is the first one
+                        // behind that barrier): half of the tile there, a quarter each behind the next two stretches
+                        if constexpr (ST == 3) { if (ahead) issue_part(i + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * Q>{}); }
+#endif
+                    } else if constexpr (ST == 5) {
+                        if (ahead) issue_part(i + 1, std::integral_constant<int, 2 * Q>{}, std::integral_constant<int, 3 * Q>{});
+                    } else if constexpr (ST == 6) {
+                        if (ahead) issue_part(i + 1, std::integral_constant<int, 3 * Q>{}, std::integral_constant<int, 4 * Q>{});
                     }
-                });
+                };
+#ifdef SPEC_TEAM_NO_STRIPX
+                rest_of_line(v, line_of(i), requests);
+#else
+                rest_of_line_sx(v, line_of(i), requests);
+#endif
                 if (!ahead && i + 1 < my_lines) {  // the column side is not ahead: wait for it here
                     PROF_T0();
                     PROF_INC(5);
