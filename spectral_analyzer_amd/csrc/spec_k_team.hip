@@ -41,7 +41,7 @@ constexpr long long TEAM_SPIN_LIMIT = 200000000ll;  // wall_clock64 ticks (100 M
 
 // sub-transform of 2^L points by T = 2^L / 8 threads, radices 8 x 8 x (M / 64)
 template <int L, int WG> struct TP {
-    static_assert(L == 7 || L == 8, "sub-transforms of 128 or 256 points");
+    static_assert(L == 7 || L == 8, "sub-transforms of 128 or 256 points");  // T = 16 or 32 threads: never more than a wave
     static_assert(WG == 256 || WG == 512, "workgroups of 256 or 512 threads");
     static constexpr int M = 1 << L, T = M / TE, C = WG / T;  // C sub-transforms (columns / rows) per tile
     static constexpr int R2 = M / 64, S2 = TE / R2;
@@ -105,6 +105,14 @@ __device__ __forceinline__ bool team_wait(const uint32_t *ctr, uint32_t target, 
 }
 
 template <typename R> __device__ __forceinline__ void ctw(cx<R> &u, const cx<R> w) { u = cmul(u, w); }
+
+// An LDS exchange whose writes and reads stay inside one wave needs no s_barrier: a wave's DS operations complete in
+// issue order; this only keeps the compiler from moving them across each other (as v2_sync of spec_v2.h).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // passes 1 and 2 of the 8 x 8 x R2 plan on the registers of butterfly index t (pass 0 is a bare dft8)
 template <typename R, int L, int WG> __device__ __forceinline__ void pass1(cx<R> (&v)[TE], int t, const cx<R> *tab) {
@@ -592,17 +600,20 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     PROF_ADD(4);
                     if (tid == 0 && pending != NONE)
                         __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here
-                    __syncthreads();
+                    // was the slot free when the poll was taken?  (first lines: nobody has used it yet.)  The poll of
+                    // line i landed in word i & 1 before wave 0 came to the barrier above; that word is rewritten two
+                    // lines on
+                    const bool slot_free = round == 0 || (pending != NONE && (int32_t)(pland[32 * (i & 1u)] - NT * round) >= 0);
+                    // Thread roles change here: from now on the T threads of a column are neighbours in one wave, and a
+                    // wave reads and writes only the rows of its own columns -- the second exchange needs no barrier
+                    xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
+                    wave_sync();
 #ifndef SPEC_ABL_TEAM_NOFFT
                     if constexpr (TWREG) twr.pass1(v);
                     else pass1<R, L1, WG>(v, t1, tab);
 #endif
                     xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
-                    // was the slot free when the poll was taken?  (first lines: nobody has used it yet)
-                    if (tid == 0) s_flag = round == 0 || (pending != NONE && (int32_t)(pland[0] - NT * round) >= 0);
-                    __syncthreads();
-                    const bool slot_free = s_flag != 0;
+                    wave_sync();
                     xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
                     finish(v);
                     // cur <- line i + 1: its rows were requested a whole line ago (behind the last line: unused)
@@ -622,7 +633,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     if (!slot_free && !team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
                     PROF_ADD(3);
 #endif
-                    if (tid == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, pland_addr);  // before the stores
+                    if (tid == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, pland_addr + 128u * ((i + 1) & 1u));  // before the stores
                     cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
                     asm volatile("" ::: "memory");
 #pragma unroll
@@ -685,14 +696,14 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #endif
                 xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
                 __syncthreads();
-                xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here
-                __syncthreads();
+                xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here: a column's threads in one wave
+                wave_sync();
 #ifndef SPEC_ABL_TEAM_NOFFT
                 if constexpr (TWREG) twr.pass1(v);
                 else pass1<R, L1, WG>(v, t1, tab);
 #endif
                 xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
-                __syncthreads();
+                wave_sync();
                 xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
                 finish(v);
 #ifndef SPEC_ABL_TEAM_NOWAIT
