@@ -124,7 +124,8 @@ void *spec_stream(const spec_ctx *ctx);
  *                     with the two-launch path behind it as a guarded fall-back; 0 = two-launch path only; 2 = the
  *                     persistent launch for any number of lines and no fall-back (the call then waits for the
  *                     kernel and returns SPEC_EDEVICE if one of its bounded waits timed out)
- *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 3)
+ *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 2: the slots share the
+ *                     XCD's 4 MiB L2 with the input and output streams; 3 measured 5 % slower, 4 20 %)
  *   "large_wg" = 256 | 512  threads per workgroup of the persistent launch (default 512: one workgroup per CU, 16-bin =
  *                     128-byte output runs; 256: two per CU, one column and one row workgroup on every CU -- measured
  *                     slower, kept for tests)

@@ -58,7 +58,7 @@ struct spec_ctx {
     void *team_sync = nullptr;    size_t team_sync_bytes = 0;     //                   tickets, ring counters, abort word    // spec_welch_psd_planar_f64: interleaved copy of the burst
     // tuning / testing knobs (spec_set_option)
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
-    int64_t opt_large_team = 1, opt_large_ring = 3, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
+    int64_t opt_large_team = 1, opt_large_ring = 2, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
     int64_t opt_welch_two_pass = 0;
     int n_cu = 256;
     // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
