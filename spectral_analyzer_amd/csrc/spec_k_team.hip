@@ -395,6 +395,8 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_flag, s_next;
     __shared__ uint32_t s_info[4];
+    __shared__ uint32_t s_arrive;  // column side: waves whose stores of the pending line are in L2 (monotonic)
+    constexpr uint32_t WAVES = WG / 64;
     double *s_dbt = reinterpret_cast<double *>(smem + LD::DBT_OFF);
 #ifdef SPEC_TEAM_PROF
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // phase stamps of lane 0 (tools/team_prof.py)
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     // HW_REG_HW_ID bits 8..15 (CU, shader array, shader engine); were that key ever shared by two CUs the roles
     // would still come out in equal numbers, only the pairing would be imperfect.
     constexpr bool PAIRED = WG == 256;
+    if (tid == 0) s_arrive = 0;
     if (tid == 0) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -591,15 +594,15 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #endif
                     xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
                     // the previous line's stores (and the poll before them) have had this long: wait for them, not
-                    // for the NLD loads issued behind them, then announce that line behind the exchange's barrier
+                    // for the NLD loads issued behind them; the last wave to see its stores done announces the line
                     PROF_T0();
                     vm_wait<NLD>();
+                    if (lane == 0 && pending != NONE && atomicAdd(&s_arrive, 1u) + 1 == WAVES * i)
+                        __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     PROF_ADD(1);
                     PROF_T0();
                     __syncthreads();
                     PROF_ADD(4);
-                    if (tid == 0 && pending != NONE)
-                        __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // was the slot free when the poll was taken?  (first lines: nobody has used it yet.)  The poll of
                     // line i landed in word i & 1 before wave 0 came to the barrier above; that word is rewritten two
                     // lines on
@@ -644,8 +647,8 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     __syncthreads();  // this line's last LDS reads | the next line's first LDS writes
                 }
                 vm_wait<0>();
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0 && atomicAdd(&s_arrive, 1u) + 1 == WAVES * my_lines)
+                    __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef SPEC_TEAM_PROF
                 pf[0] = __builtin_readcyclecounter() - pf_begin;
 #endif
