@@ -11,19 +11,24 @@
 //     step), NT "column" workgroups and NT "row" workgroups.  Teams are built from the XCD ids the hardware
 //     reports, never from blockIdx, so the result does not depend on how the dispatcher places workgroups --
 //     a different placement only changes who is in which team; workgroups left over on an XCD exit.
-//   * a team owns a contiguous range of lines and a ring of RING line-sized slots of intermediate.  Column
-//     workgroup c: 8-wide tile of columns n2, N1-point FFTs over n1 (input rows N2 samples apart), times
+//   * a team owns a contiguous range of lines and a ring of RING line-sized slots of intermediate (two by default:
+//     the slots share the L2 with the streams, and a line that stays put is rewritten there before its write-back).
+//     Column workgroup c: C-wide tile of columns n2 (C = 16 for 512 threads), N1-point FFTs over n1 (input rows N2 samples apart), times
 //     W_N^(n2 k1), into slot[line % RING] as [n2][k1]; it keeps its registers across lines, so at 50 % overlap
 //     half of the next tile is a register move, and the next line's rows are requested before the current FFT.
-//     Row workgroup r: 8-wide tile of rows k1, N2-point FFTs over n2, epilogue (SS:76-82), X[k1 + N1 k2] out.
+//     Row workgroup r: C-wide tile of rows k1, N2-point FFTs over n2, epilogue (SS:76-82), X[k1 + N1 k2] out.
 //   * flow control, per team and ring slot: doneA counts column tiles stored, doneB row tiles read.  A row
 //     workgroup starts line i when doneA == NT (i / RING + 1); a column workgroup may overwrite the slot for
 //     line i when doneB == NT (i / RING).  No full barrier: the column side runs up to RING lines ahead.
 //   * visibility inside the XCD: the column side's plain stores are write-through in the CU's L1 and land in
-//     the XCD's L2; each storing wave waits vmcnt(0), the workgroup barriers, one lane adds to doneA (agent-scope
-//     atomic).  The row side polls doneA with sc1 loads and reads the slot with sc1 loads (L1 bypass, L2 served;
+//     the XCD's L2; each storing wave waits for them (counted vmcnt), and the last wave to do so adds to doneA
+//     (agent-scope atomic).  The row side polls doneA with sc1 loads and reads the slot with sc1 loads (L1 bypass, L2 served;
 //     MI355X_MICROARCH "Workgroup dispatch, XCD placement & inter-workgroup visibility").  The slot is
 //     rewritten every RING lines and stays dirty in L2: it costs L2 bandwidth, not HBM bandwidth.
+//   * a line's three passes need two LDS exchanges per side.  Row side: the first one lives in the landing strips of
+//     the LDS-DMA loads (after pass 0 every wave writes only its own strip), the second in the line buffers; column
+//     side: the first in the line buffers, the second stays inside a wave (after the role change a column's threads
+//     are neighbours).  Two workgroup barriers per line and side.
 //   * every spin is bounded (wall clock): on a timeout -- the grid was not co-resident, e.g. the GPU is
 //     shared -- the workgroup raises the abort word and every workgroup leaves; the host then runs the
 //     two-launch path of spec_k_large.hip (guarded kernels that start only when the abort word is set).
