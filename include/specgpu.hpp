@@ -42,12 +42,14 @@ public:
     }
 
     // PowerSpectralDensity.calculatePsdWelch(data, fs, nfft) (AnalysisDialogController.java:308-312):
-    // returns {freq, psd}
+    // returns {freq, psd}.  psd is in dB/Hz (10 log10(P + 1e-20)) by default: the caller adds a dB offset to it
+    // (AnalysisDialogController.java:319-328), labels clicked values "dB" (:612, :626), takes the SNR as their
+    // difference (:675, :757) and reports "dB/Hz" (:751).  decibel = false gives the linear density.
     std::vector<std::vector<double>> calculatePsdWelch(const double *re, const double *im, uint64_t n, double fs,
-                                                       uint32_t nfft) const {
+                                                       uint32_t nfft, bool decibel = true) const {
         std::vector<double> f(nfft), p(nfft);
         check(spec_welch_psd_planar_f64(ctx_, re, im, 0, n, nfft, nfft > 1 ? nfft / 2 : 1, SPEC_WIN_HANN, SPEC_PSD_DENSITY,
-                                        fs, 0, f.data(), p.data()), ctx_);
+                                        fs, decibel ? 1 : 0, f.data(), p.data()), ctx_);
         return {f, p};
     }
 

@@ -101,13 +101,24 @@ public class SpectralService implements AutoCloseable {
      * Same argument shape as {@code PowerSpectralDensity.calculatePsdWelch(data, fs, nfft)} in the
      * PSD dialog: {@code data[0]} = I, {@code data[1]} = Q.  {@code nfft} is any positive length --
      * the dialog passes {@code data[0].length} for bursts shorter than 8192 samples.  Hann window,
-     * 50 % overlap, density scaling, linear power, fp64 throughout; returns {frequency axis, psd}.
+     * 50 % overlap, density scaling, fp64 throughout; returns {frequency axis, psd}.
+     *
+     * <p>Row 1 is in DECIBELS ({@code 10 log10(P + 1e-20)}, dB/Hz): that is what the caller reads.
+     * {@code AnalysisDialogController.updatePSDChart} adds a dB offset to it (lines 319-328), the
+     * clicked levels are labelled {@code "%.1f dB"} (612, 626), the SNR is their difference (675, 757)
+     * and the report prints "dB/Hz" (751).  {@link #calculatePsdWelch(double[][], double, int, boolean)}
+     * with {@code decibel = false} returns the linear power density.
      */
     public double[][] calculatePsdWelch(double[][] data, double sampleRate, int nfft) {
+        return calculatePsdWelch(data, sampleRate, nfft, true);
+    }
+
+    /** {@link #calculatePsdWelch(double[][], double, int)} with the unit of row 1 chosen by the caller. */
+    public double[][] calculatePsdWelch(double[][] data, double sampleRate, int nfft, boolean decibel) {
         double[] freq = new double[Math.max(nfft, 0)];
         double[] psd = new double[Math.max(nfft, 0)];
         nativeWelchPlanar(handle, data[0], data[1], nfft, Math.max(nfft / 2, 1), WINDOW_HANN, PSD_DENSITY,
-                sampleRate, false, freq, psd);
+                sampleRate, decibel, freq, psd);
         return new double[][] {freq, psd};
     }
 

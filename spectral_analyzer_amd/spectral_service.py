@@ -262,13 +262,16 @@ class SpectralService:
         return freq, psd
 
     def calculate_psd_welch(self, data, fs: float, nfft: int, hop: Optional[int] = None,
-                            window: int = L.WIN_HANN, scaling: int = L.PSD_DENSITY, db: bool = False):
+                            window: int = L.WIN_HANN, scaling: int = L.PSD_DENSITY, db: bool = True):
         """The call at ADC:308-312, ``PowerSpectralDensity.calculatePsdWelch(data, fs, nfft)``:
         ``data`` is ``double[2][N]`` (row 0 = I, row 1 = Q); returns ``[freq, psd]`` like the
         reference's two rows (doubles, fp64 pipeline).  ``nfft`` is any integer >= 1: the dialog
         passes the burst length for bursts shorter than 8192 samples (ADC:303-307).  Window /
         overlap / scaling are explicit because JDSP's are not known (defaults: Hann, 50 %,
-        density, linear)."""
+        density).  Row 1 is in dB (``10 log10(P + 1e-20)``) by default, because that is how the
+        caller reads it: an additive dB offset (ADC:319-328), ``"%.1f dB"`` marker labels
+        (ADC:612, 626), SNR = difference of two levels (ADC:675, 757), "dB/Hz" in the report
+        (ADC:751); ``db=False`` returns the linear density."""
         keep, pre, pim, n, dev = self._planar(data)  # host double[2][N] or a device tensor (the down-converter's)
         hop = int(max(nfft // 2, 1) if hop is None else hop)
         freq = np.empty(max(int(nfft), 0), dtype=np.float64)

@@ -237,14 +237,24 @@ int main(void) {
         const int n = lens[c];
         double *f = (double *)calloc(n, 8), *p = (double *)calloc(n, 8), *f2 = (double *)calloc(n, 8), *p2 = (double *)calloc(n, 8);
         fake_obj af = mk_array(f, n, 8), ap = mk_array(p, n, 8);
-        SS(nativeWelchPlanar)(env, NULL, h, &a_re, &a_im, n, n / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY, 250e3, 0, &af, &ap);
+        /* decibel = JNI_TRUE: what SpectralService.calculatePsdWelch(data, fs, nfft) passes -- the dialog reads
+         * row 1 as dB (ADC:319-328, 612, 626, 675, 751) */
+        SS(nativeWelchPlanar)(env, NULL, h, &a_re, &a_im, n, n / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY, 250e3, 1, &af, &ap);
         expect_clean("calculatePsdWelch");
         CHECK(spec_welch_psd_planar_f64(ref, re, im, 0, BURST, (uint32_t)n, (uint32_t)n / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY,
-                                        250e3, 0, f2, p2) == SPEC_OK, "abi: %s", spec_last_error(ref));
+                                        250e3, 1, f2, p2) == SPEC_OK, "abi: %s", spec_last_error(ref));
         CHECK(!memcmp(f, f2, (size_t)n * 8) && !memcmp(p, p2, (size_t)n * 8), "calculatePsdWelch(nfft = %d) differs", n);
-        double peak = 0;
-        for (int i = 0; i < n; ++i) peak = p[i] > peak ? p[i] : peak;
+        /* and it IS 10 log10 of the linear row */
+        CHECK(spec_welch_psd_planar_f64(ref, re, im, 0, BURST, (uint32_t)n, (uint32_t)n / 2, SPEC_WIN_HANN, SPEC_PSD_DENSITY,
+                                        250e3, 0, f2, p2) == SPEC_OK, "abi: %s", spec_last_error(ref));
+        double peak = 0, worst = 0;
+        for (int i = 0; i < n; ++i) {
+            peak = p2[i] > peak ? p2[i] : peak;
+            const double d = fabs(p[i] - 10.0 * log10(p2[i] + 1e-20));
+            worst = d > worst ? d : worst;
+        }
         CHECK(peak > 0, "calculatePsdWelch(nfft = %d) returned nothing", n);
+        CHECK(worst <= 1e-9, "calculatePsdWelch(nfft = %d): row 1 is not 10 log10(P + 1e-20) (off by %g dB)", n, worst);
         free(f); free(p); free(f2); free(p2);
     }
     double first_re = re[0];

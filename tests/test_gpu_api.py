@@ -360,8 +360,14 @@ def test_calculate_psd_welch_call_shape(svc, oracle):
     f_ref, p_ref = scipy.signal.welch(x, fs, window="hann", nperseg=nfft, noverlap=nfft // 2, nfft=nfft,
                                       detrend=False, return_onesided=False, scaling="density")
     assert np.allclose(out[0], np.fft.fftshift(f_ref))
-    assert np.abs(out[1] - np.fft.fftshift(p_ref)).max() <= 1e-6 * p_ref.max()
+    # row 1 is what the caller reads -- decibels (ADC:319-328 additive dB offset, :612/:626 "%.1f dB" labels,
+    # :675 SNR = difference, :751 "dB/Hz"): 10 log10(P + 1e-20), the floor of include/specgpu.h
+    db_ref = 10 * np.log10(np.fft.fftshift(p_ref) + 1e-20)
+    assert np.abs(out[1] - db_ref).max() <= 1e-5            # dB; 1e-6 relative in power is 4.3e-6 dB
     assert int(np.argmax(out[1])) == int(round(0.11 * nfft)) + nfft // 2
+    lin = svc.calculate_psd_welch(data, fs, nfft, db=False)  # the knob: linear density
+    assert np.abs(lin[1] - np.fft.fftshift(p_ref)).max() <= 1e-6 * p_ref.max()
+    assert np.abs(10 * np.log10(lin[1] + 1e-20) - out[1]).max() <= 1e-9
     with pytest.raises(IndexError):                      # shorter than nfft: the caller picks nfft (ADC:303-307)
         svc.calculate_psd_welch(data[:, :100], fs, nfft)
     with pytest.raises(ValueError):
@@ -378,8 +384,11 @@ def test_welch_any_length(svc, oracle, n):
     x = rng.normal(size=n) + 1j * rng.normal(size=n) + 2 * np.exp(2j * np.pi * 0.2 * np.arange(n))
     data = np.stack([x.real, x.imag])
     window = sa.WIN_RECT if n == 1 else sa.WIN_HANN          # a one-point Hann window is 0
-    out = svc.calculate_psd_welch(data, fs, n, window=window)
+    out = svc.calculate_psd_welch(data, fs, n, window=window, db=False)
+    out_db = svc.calculate_psd_welch(data, fs, n, window=window)          # the default: the dB row the dialog reads
     assert out.shape == (2, n) and out.dtype == np.float64
+    assert np.array_equal(out_db[0], out[0])
+    assert np.abs(out_db[1] - 10 * np.log10(out[1] + 1e-20)).max() <= 1e-9
     iq = np.ascontiguousarray(data.T).astype("<f8").tobytes()
     f_ref, p_ref = oracle.welch_psd(np.frombuffer(iq, np.uint8), 0, "cf64_le", n, max(n // 2, 1), 1, window,
                                     oracle.PSD_DENSITY, fs)
