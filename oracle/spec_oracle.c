@@ -109,10 +109,172 @@ void so_decode_sample(const uint8_t *buf, uint64_t start_byte, uint64_t i,
     decode_kind(buf, start_byte, i, dtype_kind(dt, cf64_decode), so_is_big_endian(dt), re, im);
 }
 
-/* commons-math3 3.6.1 FastFourierTransformer.transformInPlace, STANDARD,
- * FORWARD, restated: bit-reversal shuffle, then log2(n) radix-2 stages with
- * w = exp(-2 pi i j / len).  Twiddles are evaluated in long double and rounded
- * to double once (the library uses precomputed double tables). */
+/* ---------------------------------------------------------------------------------------------
+ * The transform the reference calls (SpectralService.java:23,68, build.gradle:148):
+ *   new FastFourierTransformer(DftNormalization.STANDARD).transform(Complex[], TransformType.FORWARD)
+ * of org.apache.commons:commons-math3:3.6.1.  The jar and its source are not in the build image; what
+ * follows restates the PUBLISHED algorithm of FastFourierTransformer.transformInPlace operation by
+ * operation, in the published order of the floating-point operations (the file is compiled with
+ * -ffp-contract=off: Java never fuses a multiply into an add):
+ *   1. n == 1: nothing; n == 2: the two-term butterfly;
+ *   2. bitReversalShuffle2 on the real and imaginary arrays;
+ *   3. a dedicated 4-term first stage (no multiplications);
+ *   4. for n0 = 8, 16, ... n: the butterflies of every block, with the twiddle kept as a running product
+ *      wSubN0ToR *= wSubN0, seeded with 1 and multiplied by the stage's root of unity W_SUB_N_R/I[log2 n0]
+ *      (two hexadecimal double tables of 63 entries in the library: cos(2 pi / 2^k), -sin(2 pi / 2^k)
+ *      evaluated at the double 2 pi / 2^k; regenerated by tools/gen_cm3_roots.py, which also checks the
+ *      entries known from the published source).  The recurrence makes twiddle r of a stage carry an error
+ *      of about r eps -- the reference's lines are LESS accurate than an exact-twiddle transform, and the
+ *      oracle reproduces that (so_fft_forward_exact below is kept as the accuracy yardstick);
+ *   5. STANDARD + FORWARD: no scaling.
+ * Complex.abs() (SS:80) is the scaled form |a| sqrt(1 + (b/a)^2) with a the component of larger magnitude,
+ * not hypot(); cm3_abs restates it including its NaN / infinity / zero branches.
+ * ------------------------------------------------------------------------------------------- */
+static const double CM3_W_SUB_N_R[63] = {
+    0x1.0000000000000p+0, -0x1.0000000000000p+0, 0x1.1a62633145c07p-54,
+    0x1.6a09e667f3bcdp-1, 0x1.d906bcf328d46p-1, 0x1.f6297cff75cb0p-1,
+    0x1.fd88da3d12526p-1, 0x1.ff621e3796d7ep-1, 0x1.ffd886084cd0dp-1,
+    0x1.fff62169b92dbp-1, 0x1.fffd8858e8a92p-1, 0x1.ffff621621d02p-1,
+    0x1.ffffd88586ee6p-1, 0x1.fffff62161a34p-1, 0x1.fffffd8858675p-1,
+    0x1.ffffff621619cp-1, 0x1.ffffffd885867p-1, 0x1.fffffff62161ap-1,
+    0x1.fffffffd88586p-1, 0x1.ffffffff62162p-1, 0x1.ffffffffd8858p-1,
+    0x1.fffffffff6216p-1, 0x1.fffffffffd886p-1, 0x1.ffffffffff621p-1,
+    0x1.ffffffffffd88p-1, 0x1.fffffffffff62p-1, 0x1.fffffffffffd9p-1,
+    0x1.ffffffffffff6p-1, 0x1.ffffffffffffep-1, 0x1.fffffffffffffp-1,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+    0x1.0000000000000p+0, 0x1.0000000000000p+0, 0x1.0000000000000p+0,
+};
+static const double CM3_W_SUB_N_I[63] = {
+    0x1.1a62633145c07p-52, -0x1.1a62633145c07p-53, -0x1.0000000000000p+0,
+    -0x1.6a09e667f3bccp-1, -0x1.87de2a6aea963p-2, -0x1.8f8b83c69a60ap-3,
+    -0x1.917a6bc29b42cp-4, -0x1.91f65f10dd814p-5, -0x1.92155f7a3667ep-6,
+    -0x1.921d1fcdec784p-7, -0x1.921f0fe670071p-8, -0x1.921f8becca4bap-9,
+    -0x1.921faaee6472dp-10, -0x1.921fb2aecb360p-11, -0x1.921fb49ee4ea6p-12,
+    -0x1.921fb51aeb57bp-13, -0x1.921fb539ecf31p-14, -0x1.921fb541ad59ep-15,
+    -0x1.921fb5439d73ap-16, -0x1.921fb544197a0p-17, -0x1.921fb544387bap-18,
+    -0x1.921fb544403c1p-19, -0x1.921fb544422c2p-20, -0x1.921fb54442a83p-21,
+    -0x1.921fb54442c73p-22, -0x1.921fb54442cefp-23, -0x1.921fb54442d0ep-24,
+    -0x1.921fb54442d15p-25, -0x1.921fb54442d17p-26, -0x1.921fb54442d18p-27,
+    -0x1.921fb54442d18p-28, -0x1.921fb54442d18p-29, -0x1.921fb54442d18p-30,
+    -0x1.921fb54442d18p-31, -0x1.921fb54442d18p-32, -0x1.921fb54442d18p-33,
+    -0x1.921fb54442d18p-34, -0x1.921fb54442d18p-35, -0x1.921fb54442d18p-36,
+    -0x1.921fb54442d18p-37, -0x1.921fb54442d18p-38, -0x1.921fb54442d18p-39,
+    -0x1.921fb54442d18p-40, -0x1.921fb54442d18p-41, -0x1.921fb54442d18p-42,
+    -0x1.921fb54442d18p-43, -0x1.921fb54442d18p-44, -0x1.921fb54442d18p-45,
+    -0x1.921fb54442d18p-46, -0x1.921fb54442d18p-47, -0x1.921fb54442d18p-48,
+    -0x1.921fb54442d18p-49, -0x1.921fb54442d18p-50, -0x1.921fb54442d18p-51,
+    -0x1.921fb54442d18p-52, -0x1.921fb54442d18p-53, -0x1.921fb54442d18p-54,
+    -0x1.921fb54442d18p-55, -0x1.921fb54442d18p-56, -0x1.921fb54442d18p-57,
+    -0x1.921fb54442d18p-58, -0x1.921fb54442d18p-59, -0x1.921fb54442d18p-60,
+};
+
+static void cm3_bit_reversal_shuffle2(double *a, double *b, uint32_t n) {
+    const uint32_t half_of_n = n >> 1;
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (i < j) {
+            double t = a[i]; a[i] = a[j]; a[j] = t;
+            t = b[i]; b[i] = b[j]; b[j] = t;
+        }
+        uint32_t k = half_of_n;
+        while (k <= j && k > 0) { j -= k; k >>= 1; }
+        j += k;
+    }
+}
+
+static void cm3_transform_in_place(double *dataR, double *dataI, uint32_t n) {
+    if (n == 1) return;
+    if (n == 2) {
+        const double srcR0 = dataR[0], srcI0 = dataI[0], srcR1 = dataR[1], srcI1 = dataI[1];
+        dataR[0] = srcR0 + srcR1; dataI[0] = srcI0 + srcI1;   /* X_0 = x_0 + x_1 */
+        dataR[1] = srcR0 - srcR1; dataI[1] = srcI0 - srcI1;   /* X_1 = x_0 - x_1 */
+        return;
+    }
+    cm3_bit_reversal_shuffle2(dataR, dataI, n);
+    /* 4-term DFT, forward.  After the shuffle positions i0 .. i3 hold x_0, x_2, x_1, x_3 of the block */
+    for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+        const uint32_t i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
+        const double srcR0 = dataR[i0], srcI0 = dataI[i0];
+        const double srcR1 = dataR[i2], srcI1 = dataI[i2];
+        const double srcR2 = dataR[i1], srcI2 = dataI[i1];
+        const double srcR3 = dataR[i3], srcI3 = dataI[i3];
+        dataR[i0] = srcR0 + srcR1 + srcR2 + srcR3;            /* X_0 = x_0 + x_1 + x_2 + x_3 */
+        dataI[i0] = srcI0 + srcI1 + srcI2 + srcI3;
+        dataR[i1] = srcR0 - srcR2 + (srcI1 - srcI3);          /* X_1 = x_0 - x_2 + j (x_3 - x_1) */
+        dataI[i1] = srcI0 - srcI2 + (srcR3 - srcR1);
+        dataR[i2] = srcR0 - srcR1 + srcR2 - srcR3;            /* X_2 = x_0 - x_1 + x_2 - x_3 */
+        dataI[i2] = srcI0 - srcI1 + srcI2 - srcI3;
+        dataR[i3] = srcR0 - srcR2 + (srcI3 - srcI1);          /* X_3 = x_0 - x_2 + j (x_1 - x_3) */
+        dataI[i3] = srcI0 - srcI2 + (srcR1 - srcR3);
+    }
+    uint32_t lastN0 = 4, lastLogN0 = 2;
+    while (lastN0 < n) {
+        const uint32_t n0 = lastN0 << 1, logN0 = lastLogN0 + 1;
+        const double wSubN0R = CM3_W_SUB_N_R[logN0], wSubN0I = CM3_W_SUB_N_I[logN0];   /* FORWARD: as tabulated */
+        /* combine the even / odd transforms of size lastN0 into one of size n0 */
+        for (uint32_t destEvenStartIndex = 0; destEvenStartIndex < n; destEvenStartIndex += n0) {
+            const uint32_t destOddStartIndex = destEvenStartIndex + lastN0;
+            double wSubN0ToRR = 1, wSubN0ToRI = 0;
+            for (uint32_t r = 0; r < lastN0; r++) {
+                const double grR = dataR[destEvenStartIndex + r], grI = dataI[destEvenStartIndex + r];
+                const double hrR = dataR[destOddStartIndex + r], hrI = dataI[destOddStartIndex + r];
+                /* dest[even + r] = Gr + WsubN0ToR Hr */
+                dataR[destEvenStartIndex + r] = grR + wSubN0ToRR * hrR - wSubN0ToRI * hrI;
+                dataI[destEvenStartIndex + r] = grI + wSubN0ToRR * hrI + wSubN0ToRI * hrR;
+                /* dest[odd + r] = Gr - WsubN0ToR Hr */
+                dataR[destOddStartIndex + r] = grR - (wSubN0ToRR * hrR - wSubN0ToRI * hrI);
+                dataI[destOddStartIndex + r] = grI - (wSubN0ToRR * hrI + wSubN0ToRI * hrR);
+                /* WsubN0ToR *= WsubN0 */
+                const double nextWsubN0ToRR = wSubN0ToRR * wSubN0R - wSubN0ToRI * wSubN0I;
+                const double nextWsubN0ToRI = wSubN0ToRR * wSubN0I + wSubN0ToRI * wSubN0R;
+                wSubN0ToRR = nextWsubN0ToRR;
+                wSubN0ToRI = nextWsubN0ToRI;
+            }
+        }
+        lastN0 = n0;
+        lastLogN0 = logN0;
+    }
+    /* normalizeTransformedData(STANDARD, FORWARD): nothing */
+}
+
+/* org.apache.commons.math3.complex.Complex.abs() */
+static double cm3_abs(double real, double imaginary) {
+    if (isnan(real) || isnan(imaginary)) return NAN;
+    if (isinf(real) || isinf(imaginary)) return INFINITY;
+    if (fabs(real) < fabs(imaginary)) {
+        if (imaginary == 0.0) return fabs(real);
+        const double q = real / imaginary;
+        return fabs(imaginary) * sqrt(1 + q * q);
+    } else {
+        if (real == 0.0) return fabs(imaginary);
+        const double q = imaginary / real;
+        return fabs(real) * sqrt(1 + q * q);
+    }
+}
+
+double so_complex_abs(double re, double im) { return cm3_abs(re, im); }
+
+int so_fft_forward_cm3(double *re, double *im, uint32_t n) {
+    if (n == 0 || (n & (n - 1)) != 0) return -1;   /* the library throws MathIllegalArgumentException */
+    cm3_transform_in_place(re, im, n);
+    return 0;
+}
+
+/* the reference's transform */
+int so_fft_forward(double *re, double *im, uint32_t n) { return so_fft_forward_cm3(re, im, n); }
+
+/* ---- the accuracy yardstick: same radix-2 structure, every twiddle exp(-2 pi i j / len) evaluated in long
+ * double and rounded to double ONCE.  Not what the reference computes; used to measure the cm3 transform's
+ * own error (tests/test_oracle.py prints it per N) and by the build-defined Welch (JDSP's transform is unknown). */
 static int make_twiddles(uint32_t n, double **wr_out, double **wi_out) {
     double *wr = (double *)malloc(sizeof(double) * (n / 2 + 1));
     double *wi = (double *)malloc(sizeof(double) * (n / 2 + 1));
@@ -154,7 +316,7 @@ static void fft_forward_tw(double *re, double *im, uint32_t n,
     }
 }
 
-int so_fft_forward(double *re, double *im, uint32_t n) {
+int so_fft_forward_exact(double *re, double *im, uint32_t n) {
     if (n == 0 || (n & (n - 1)) != 0) return -1;
     if (n == 1) return 0;
     double *wr, *wi;
@@ -173,8 +335,8 @@ static void make_window(double *w, uint32_t n, int window) {
                    : 1.0;
 }
 
-/* one line: decode (SS:40-65) -> optional window -> FFT (SS:68); leaves the
- * unshifted spectrum in re/im */
+/* one line: decode (SS:40-65) -> optional window -> FFT (SS:68); leaves the unshifted spectrum in re/im.
+ * wr == NULL: the reference's transform (cm3); otherwise the exact-twiddle yardstick with that table */
 static void line_spectrum(const uint8_t *buf, uint64_t start_byte, uint32_t nfft,
                           const char *dt, int cf64_decode, const double *win,
                           const double *wr, const double *wi,
@@ -184,25 +346,27 @@ static void line_spectrum(const uint8_t *buf, uint64_t start_byte, uint32_t nfft
         decode_kind(buf, start_byte, i, kind, be, &re[i], &im[i]);
         if (win) { re[i] *= win[i]; im[i] *= win[i]; }
     }
-    if (nfft > 1 && (nfft & (nfft - 1)) == 0) fft_forward_tw(re, im, nfft, wr, wi);
+    if (nfft > 1 && (nfft & (nfft - 1)) == 0) {
+        if (wr) fft_forward_tw(re, im, nfft, wr, wi);
+        else cm3_transform_in_place(re, im, nfft);
+    }
 }
 
 /* SpectralService.java:33-85 */
 int so_compute_magnitudes(const uint8_t *buf, uint64_t start_byte, uint32_t nfft,
                           const char *dt, int cf64_decode, double *out) {
     if (nfft == 0 || (nfft & (nfft - 1)) != 0) return -1;
-    double *re = (double *)malloc(sizeof(double) * nfft * 2), *wr, *wi;
+    double *re = (double *)malloc(sizeof(double) * nfft * 2);
     if (!re) return -1;
-    if (make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
     double *im = re + nfft;
-    line_spectrum(buf, start_byte, nfft, dt, cf64_decode, NULL, wr, wi, re, im);
+    line_spectrum(buf, start_byte, nfft, dt, cf64_decode, NULL, NULL, NULL, re, im);   /* SS:40-68 */
     uint32_t half = nfft / 2;
     for (uint32_t i = 0; i < nfft; i++) {
         uint32_t s = (i + half) % nfft;            /* SS:78 */
-        double a = hypot(re[i], im[i]);            /* Complex.abs(), SS:80 */
+        double a = cm3_abs(re[i], im[i]);          /* Complex.abs(), SS:80 */
         out[s] = 20 * log10(a + 1e-10);            /* SS:81 */
     }
-    free(re); free(wr); free(wi);
+    free(re);
     return 0;
 }
 
@@ -220,13 +384,13 @@ uint64_t so_count_lines(uint64_t capacity, uint64_t start_byte, const char *dt,
  * (nfft for the public entry; 0 lets the timing driver reuse one line). */
 static int waterfall_impl(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
                           const char *dt, int cf64_decode, uint32_t nfft, uint32_t hop,
-                          uint64_t n_lines, int window, double eof_fill, int power_out,
+                          uint64_t n_lines, int window, double eof_fill, int power_out, int fft,
                           double *out, uint64_t out_stride, double *checksum) {
     if (nfft == 0 || (nfft & (nfft - 1)) != 0 || hop == 0) return -1;
     uint64_t bps = (uint64_t)so_bytes_per_sample(dt);
-    double *re = (double *)malloc(sizeof(double) * nfft * 3), *wr, *wi;
+    double *re = (double *)malloc(sizeof(double) * nfft * 3), *wr = NULL, *wi = NULL;
     if (!re) return -1;
-    if (make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
+    if (fft == SO_FFT_EXACT && make_twiddles(nfft, &wr, &wi)) { free(re); return -1; }
     double *im = re + nfft, *win = im + nfft;
     make_window(win, nfft, window);
     uint32_t half = nfft / 2;
@@ -240,7 +404,7 @@ static int waterfall_impl(const uint8_t *buf, uint64_t capacity, uint64_t start_
             for (uint32_t i = 0; i < nfft; i++) {
                 uint32_t s = (i + half) % nfft;                      /* SS:78 */
                 if (power_out) o[s] = re[i] * re[i] + im[i] * im[i];
-                else o[s] = 20 * log10(hypot(re[i], im[i]) + 1e-10); /* SS:80-81 */
+                else o[s] = 20 * log10((fft == SO_FFT_EXACT ? hypot(re[i], im[i]) : cm3_abs(re[i], im[i])) + 1e-10); /* SS:80-81 */
             }
         } else {
             for (uint32_t i = 0; i < nfft; i++) o[i] = eof_fill;    /* MC:994-998 */
@@ -257,7 +421,16 @@ int so_waterfall(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
                  uint64_t n_lines, int window, double eof_fill, int power_out,
                  double *out) {
     return waterfall_impl(buf, capacity, start_byte, dt, cf64_decode, nfft, hop,
-                          n_lines, window, eof_fill, power_out, out, nfft, NULL);
+                          n_lines, window, eof_fill, power_out, SO_FFT_CM3, out, nfft, NULL);
+}
+
+int so_waterfall_fft(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
+                     const char *dt, int cf64_decode, uint32_t nfft, uint32_t hop,
+                     uint64_t n_lines, int window, double eof_fill, int power_out, int fft,
+                     double *out) {
+    if (fft != SO_FFT_CM3 && fft != SO_FFT_EXACT) return -1;
+    return waterfall_impl(buf, capacity, start_byte, dt, cf64_decode, nfft, hop,
+                          n_lines, window, eof_fill, power_out, fft, out, nfft, NULL);
 }
 
 int so_welch_psd(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
@@ -567,10 +740,9 @@ static void *job_main(void *p) {
     job_t *j = (job_t *)p;
     uint64_t bps = (uint64_t)so_bytes_per_sample(j->dt);
     double *line = (double *)malloc(sizeof(double) * j->nfft);
-    /* tables are built once per thread, as the reference builds its
-     * FastFourierTransformer once (SpectralService.java:23) */
+    /* the reference's own transform (commons-math3: twiddles by recurrence, no tables), SS:23,68 */
     waterfall_impl(j->buf, j->capacity, j->l0 * (uint64_t)j->hop * bps, j->dt, 1,
-                   j->nfft, j->hop, j->l1 - j->l0, j->window, -150.0, 0, line, 0,
+                   j->nfft, j->hop, j->l1 - j->l0, j->window, -150.0, 0, SO_FFT_CM3, line, 0,
                    &j->checksum);
     free(line);
     return NULL;

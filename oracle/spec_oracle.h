@@ -11,7 +11,9 @@
  *   (1) analytic known-answer tests derived from the formulas at
  *       SpectralService.java:40-82 (tests/test_oracle.py, K1..K9), and
  *   (2) two independent implementations of the DFT / Welch definitions
- *       (numpy.fft.fft, scipy.signal.welch), see oracle/spec_oracle.py.
+ *       (numpy.fft.fft, scipy.signal.welch), see oracle/spec_oracle.py, and
+ *   (3) the literals of commons-math3's root-of-unity tables known from its published source
+ *       (tools/gen_cm3_roots.py).
  *
  * Reference files restated (paths relative to the reference repo root,
  * src/main/java/net/kcundercover/spectral_analyzer/...):
@@ -28,7 +30,12 @@
  * published definitions):
  *   org.apache.commons:commons-math3:3.6.1  FastFourierTransformer(STANDARD).
  *       transform(x, FORWARD): X[k] = sum_n x[n] exp(-2 pi i k n / N), unscaled,
- *       power-of-two N, in-place radix-2 after bit reversal.
+ *       power-of-two N.  Restated as PUBLISHED (so_fft_forward_cm3): bitReversalShuffle2, a
+ *       4-term first stage, then per stage a multiplicative twiddle recurrence seeded from the
+ *       library's 63-entry root tables; Complex.abs() in its scaled sqrt(1 + q^2) form.  The
+ *       recurrence costs accuracy (twiddle r of a stage is off by ~r eps): the reference's lines
+ *       carry that error and so does this oracle; so_fft_forward_exact (twiddles evaluated in long
+ *       double, rounded once) is kept beside it as the accuracy yardstick.
  *   com.github.GassiusODude:jdsp:v1.3.1  PowerSpectralDensity.calculatePsdWelch:
  *       source absent -> this file defines the build's PSD (Welch, see
  *       so_welch_psd) and is checked against scipy.signal.welch only.
@@ -63,9 +70,20 @@ void so_decode_sample(const uint8_t *buf, uint64_t start_byte, uint64_t i,
                       const char *datatype, int cf64_decode,
                       double *re, double *im);
 
-/* commons-math3 FastFourierTransformer(STANDARD), FORWARD: in-place, unscaled,
- * n must be a power of two (returns -1 otherwise, where the library throws). */
+/* which transform a waterfall is computed with */
+enum { SO_FFT_CM3 = 0,   /* the reference's: commons-math3 3.6.1 as published (twiddle recurrence) */
+       SO_FFT_EXACT = 1  /* yardstick: same radix-2 structure, exact twiddles, hypot() */ };
+
+/* commons-math3 3.6.1 FastFourierTransformer(STANDARD), FORWARD, restated as published: in-place,
+ * unscaled, n must be a power of two (returns -1 otherwise, where the library throws).
+ * so_fft_forward is the same function (the transform the reference calls, SS:68). */
+int so_fft_forward_cm3(double *re, double *im, uint32_t n);
 int so_fft_forward(double *re, double *im, uint32_t n);
+/* accuracy yardstick, NOT the reference's arithmetic: every twiddle evaluated in long double and
+ * rounded to double once */
+int so_fft_forward_exact(double *re, double *im, uint32_t n);
+/* org.apache.commons.math3.complex.Complex.abs() (SS:80), restated */
+double so_complex_abs(double re, double im);
 
 /* SpectralService.java:33-85 -- one spectrogram line, out[nfft]:
  * out[(i + n/2) % n] = 20 log10(|X_i| + 1e-10). Returns 0, or -1 on bad nfft. */
@@ -83,6 +101,12 @@ int so_waterfall(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
                  uint32_t hop, uint64_t n_lines, int window, double eof_fill,
                  int power_out, double *out);
 
+/* so_waterfall with the transform chosen: SO_FFT_CM3 (= so_waterfall) or SO_FFT_EXACT */
+int so_waterfall_fft(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
+                     const char *datatype, int cf64_decode, uint32_t nfft,
+                     uint32_t hop, uint64_t n_lines, int window, double eof_fill,
+                     int power_out, int fft, double *out);
+
 /* Number of whole lines available: floor((S - nfft)/hop) + 1 for S samples
  * from start_byte to capacity (0 when S < nfft). */
 uint64_t so_count_lines(uint64_t capacity, uint64_t start_byte,
@@ -94,7 +118,9 @@ uint64_t so_count_lines(uint64_t capacity, uint64_t start_byte,
  *      = mean_s |FFT(w x_s)[k]|^2 / (sum w)^2        (SPECTRUM)
  * two-sided, fftshifted so index 0 is -fs/2; freq[k] = (k - N/2) fs / N
  * (AnalysisDialogController.java:324-328 adds centerFreq to row 0).
- * psd_db != 0 returns 10 log10(P + 1e-20).  Returns 0 / -1. */
+ * psd_db != 0 returns 10 log10(P + 1e-20).  JDSP's own transform is unknown, so the estimate uses the
+ * exact-twiddle transform (so_fft_forward_exact; a plain DFT for lengths that are not powers of
+ * two).  Returns 0 / -1. */
 int so_welch_psd(const uint8_t *buf, uint64_t capacity, uint64_t start_byte,
                  const char *datatype, int cf64_decode, uint32_t nfft,
                  uint32_t hop, uint32_t n_seg, int window, int scaling,

@@ -3,9 +3,11 @@
 Two independent restatements of the reference hot path live here:
 
 * ``C``   -- ctypes bindings to ``oracle/libspec_oracle.so`` (spec_oracle.c), the
-  fp64 radix-2 restatement of ``SpectralService.computeMagnitudes``
-  (services/SpectralService.java:33-85) and of the ``MainController.updateDisplay``
-  line loop (controllers/MainController.java:980-999).
+  fp64 restatement of ``SpectralService.computeMagnitudes``
+  (services/SpectralService.java:33-85) -- with commons-math3 3.6.1's transform restated as
+  published (bit-reversal shuffle, 4-term first stage, twiddles by recurrence; ``FFT_CM3``) and
+  an exact-twiddle transform beside it as the accuracy yardstick (``FFT_EXACT``) -- and of the
+  ``MainController.updateDisplay`` line loop (controllers/MainController.java:980-999).
 * ``np_*`` -- a numpy restatement that uses ``numpy.fft.fft`` (a different FFT
   implementation) so the two can be checked against each other.
 
@@ -28,6 +30,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libspec_oracle.so")
 
 WIN_RECT, WIN_HANN = 0, 1
+FFT_CM3, FFT_EXACT = 0, 1   # the reference's commons-math3 transform / the exact-twiddle yardstick
 PSD_DENSITY, PSD_SPECTRUM = 0, 1
 
 _lib = None
@@ -52,6 +55,12 @@ def lib() -> C.CDLL:
         L.so_bytes_per_sample.argtypes = [C.c_char_p]
         L.so_is_big_endian.argtypes = [C.c_char_p]
         L.so_fft_forward.argtypes = [dp, dp, C.c_uint32]
+        L.so_fft_forward_cm3.argtypes = [dp, dp, C.c_uint32]
+        L.so_fft_forward_exact.argtypes = [dp, dp, C.c_uint32]
+        L.so_complex_abs.argtypes = [C.c_double, C.c_double]
+        L.so_complex_abs.restype = C.c_double
+        L.so_waterfall_fft.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_uint32,
+                                       C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_int, dp]
         L.so_compute_magnitudes.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_int, dp]
         L.so_waterfall.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_uint32,
                                    C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_int, dp]
@@ -91,13 +100,20 @@ def is_big_endian(datatype: str) -> bool:
     return bool(lib().so_is_big_endian(datatype.encode()))
 
 
-def fft_forward(x: np.ndarray) -> np.ndarray:
+def fft_forward(x: np.ndarray, fft: int = FFT_CM3) -> np.ndarray:
+    """FFT_CM3: commons-math3 3.6.1 as published (the reference's transform); FFT_EXACT: the yardstick."""
     re = np.ascontiguousarray(x.real, dtype=np.float64).copy()
     im = np.ascontiguousarray(x.imag, dtype=np.float64).copy()
-    rc = lib().so_fft_forward(re.ctypes.data, im.ctypes.data, len(re))
+    fn = lib().so_fft_forward_cm3 if fft == FFT_CM3 else lib().so_fft_forward_exact
+    rc = fn(re.ctypes.data, im.ctypes.data, len(re))
     if rc:
         raise ValueError("nfft must be a power of two")
     return re + 1j * im
+
+
+def complex_abs(re: float, im: float) -> float:
+    """Complex.abs() of commons-math3 (SS:80)."""
+    return float(lib().so_complex_abs(float(re), float(im)))
 
 
 def compute_magnitudes(buf, start_byte: int, nfft: int, datatype: str, cf64_decode: bool = False) -> np.ndarray:
@@ -120,11 +136,13 @@ def count_lines(capacity: int, start_byte: int, datatype: str, nfft: int, hop: i
 
 def waterfall(buf, start_byte: int, datatype: str, nfft: int, hop: int, n_lines: int,
               window: int = WIN_RECT, eof_fill: float = -150.0, power: bool = False,
-              cf64_decode: bool = True) -> np.ndarray:
+              cf64_decode: bool = True, fft: int = FFT_CM3) -> np.ndarray:
+    """MC:980-999 around SS:33-85.  ``fft=FFT_CM3`` (default): the reference's own transform and
+    ``Complex.abs()``; ``FFT_EXACT``: the exact-twiddle yardstick with ``hypot``."""
     b = _bytes_view(buf)
     out = np.empty((n_lines, nfft), dtype=np.float64)
-    rc = lib().so_waterfall(b.ctypes.data, b.size, start_byte, datatype.encode(), int(cf64_decode),
-                            nfft, hop, n_lines, window, eof_fill, int(power), out.ctypes.data)
+    rc = lib().so_waterfall_fft(b.ctypes.data, b.size, start_byte, datatype.encode(), int(cf64_decode),
+                                nfft, hop, n_lines, window, eof_fill, int(power), int(fft), out.ctypes.data)
     if rc:
         raise ValueError("bad nfft/hop")
     return out

@@ -3,7 +3,9 @@
 
 The reference (Java, third-party FFT jar, no JDK in the build image) cannot be
 run to produce vectors, and it ships none.  These fixtures are therefore made
-from the CPU oracle (oracle/spec_oracle.c) AFTER checking it against an
+from the CPU oracle (oracle/spec_oracle.c) -- since round 3 with commons-math3
+3.6.1's transform restated as published (twiddles by recurrence, Complex.abs()),
+i.e. the reference's own rounding behaviour -- AFTER checking it against an
 independent FFT (numpy.fft) on the very same input; each file holds the input
 bytes, the parameters and the expected dB lines (float64).
 

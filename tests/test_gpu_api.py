@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import spectral_analyzer_amd as sa
-from test_gpu_parity import check_fp32, check_fp64
+from test_gpu_parity import check_fp32, check_fp64, fp64_pow_tol
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -113,7 +113,7 @@ def test_fp64_outputs_strict(svc, oracle, datatype, nfft):
         check_fp64(got, ref)
         p_ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window, power=True)
         p = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_POW_F64)
-        assert np.abs(p - p_ref).max() <= 1e-12 * p_ref.max()
+        assert np.abs(p - p_ref).max() <= fp64_pow_tol(nfft) * p_ref.max()
 
 
 @pytest.mark.parametrize("nfft", [512, 4096])

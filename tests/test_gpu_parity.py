@@ -10,16 +10,19 @@ fp32 pipeline (reference is fp64):  with M = max_k |X[k]| of the line,
   gets weaker: <= 4e-4 dB measured at 1e-3 M, 1-2e-3 dB at 1e-4 M.  SURVEY 8(c) / BASELINE.md 3
   state 2e-3 dB down to 1e-4 M, written before anything was measured; the two-tier statement
   above is the one the build holds, and test_observed_fp32_error_per_tier prints the maxima)
-fp64 pipeline (DB20_F64 / cf64), the same two forms with fp64's epsilon:
-    * every bin with |X| >= 1e-9 * M:  | |X|_gpu - |X|_ref |  <=  (8e-15 * log2(N) + 5e-14) * M
-      (the fp32 bound scaled by eps64 / eps32, plus what the dB value itself can carry: the fp64 log epilogues
-      are good to 3e-13 dB = 3.5e-14 relative, and the comparison goes through the dB values)
-    * bins with |X| >= 1e-5 * M:       | dB_gpu - dB_ref |    <=  1e-9 dB
-  SURVEY 8(c) states the 1e-9 dB down to 1e-9 M; no fp64 transform can deliver that: both the oracle
-  and the GPU carry an absolute error of a few 1e-16 M per bin, which on a bin of 1e-6 M is already
-  1e-10 relative = 1e-9 dB (first seen on 1 of 2.4 million bins of a 16384-point case whose noise
-  floor happened to have a deep null).  Hence the dB form holds from 1e-5 M up and the linear form
-  covers every bin.
+fp64 pipeline (DB20_F64 / cf64 / spec_compute_magnitudes) -- stated AGAINST THE REFERENCE'S ALGORITHM, and therefore
+N-dependent.  The oracle restates commons-math3 3.6.1's transform as published: twiddles are running products
+(wSubN0ToR *= wSubN0), so twiddle r of a stage carries about r eps of error and the reference's own line is off by up to
+REF(N) = 4e-17 N (relative to the line's peak M; measured 0.6 .. 1.5e-17 N, printed by tests/test_oracle.py::
+test_cm3_transform_own_error_per_length).  The GPU pipeline uses exact twiddles (own error OWN(N) = 8e-15 log2 N + 5e-14,
+the fp32 bound scaled by eps64 / eps32 plus what a dB value good to 3e-13 dB can carry), so what the comparison can hold is
+    * every bin with |X| >= 1e-9 M:  | |X|_gpu - |X|_ref |  <=  max(OWN(N), REF(N)) M         (fp64_tol)
+      (REF takes over from 4096 points on: 1.6e-13 at 4096, 2.6e-12 at 65536)
+    * bins with |X| >= 1e-5 M:       | dB_gpu - dB_ref |    <=  max(1e-9, 1e-12 N) dB          (fp64_db_tol)
+      (measured reference-vs-exact: 1.8e-10 dB at 4096, 1.3e-9 at 8192, 1.2e-8 at 65536)
+  Up to 2048 points this is the round-2 statement (1e-9 dB); beyond, the 1e-9 dB of rounds 1-2 was a statement about the
+  builder's exact-twiddle oracle, not about the Java reference, and is withdrawn.  SURVEY 8(c)'s "1e-9 dB down to 1e-9 M"
+  cannot hold against any fp64 transform (an absolute error of a few 1e-16 M on a bin of 1e-6 M is already 1e-9 dB).
 """
 import numpy as np
 import pytest
@@ -44,6 +47,21 @@ def check_fp32(db_gpu, db_ref, nfft):
     return lin_err.max(), db_abs[mag_r >= 1e-3 * M].max(), db_abs[mag_r >= 1e-4 * M].max()
 
 
+def fp64_tol(nfft):
+    """Linear fp64 tolerance relative to the line's peak: max(the pipeline's own bound, the reference transform's own error)."""
+    return max(8e-15 * np.log2(max(nfft, 2)) + 5e-14, 4e-17 * nfft)
+
+
+def fp64_db_tol(nfft):
+    """dB tolerance on bins >= 1e-5 M."""
+    return max(1e-9, 1e-12 * nfft)
+
+
+def fp64_pow_tol(nfft):
+    """|X|^2 outputs, relative to the peak power: twice the linear figure, never under 1e-12."""
+    return max(1e-12, 2 * fp64_tol(nfft) if nfft >= 4096 else 1e-12)
+
+
 def check_fp64(db_gpu, db_ref):
     nfft = db_ref.shape[-1]
     mag_r = 10.0 ** (db_ref / 20.0)
@@ -51,10 +69,10 @@ def check_fp64(db_gpu, db_ref):
     M = mag_r.max(axis=1, keepdims=True)
     seen = mag_r >= 1e-9 * M            # below that the +1e-10 of SS:81 takes over
     lin = (np.abs(mag_g - mag_r) / M)[seen]
-    tol = 8e-15 * np.log2(max(nfft, 2)) + 5e-14
+    tol = fp64_tol(nfft)
     assert lin.max() <= tol, "fp64 linear error %.3g M > %.3g M" % (lin.max(), tol)
     err = np.abs(db_gpu - db_ref)[mag_r >= 1e-5 * M]
-    assert err.max() <= 1e-9, "fp64 dB error %.3g" % err.max()
+    assert err.max() <= fp64_db_tol(nfft), "fp64 dB error %.3g > %.3g" % (err.max(), fp64_db_tol(nfft))
 
 
 @pytest.mark.parametrize("datatype", DTYPES)
@@ -139,7 +157,7 @@ def test_fp64_family_all_variants(svc, oracle, nfft, datatype, hop_div, window):
     check_fp64(got[:-1], ref[:-1])
     pw = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_POW_F64)
     ref_pw = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window, power=True)
-    assert np.abs(pw - ref_pw).max() <= 1e-12 * ref_pw.max()
+    assert np.abs(pw - ref_pw).max() <= fp64_pow_tol(nfft) * ref_pw.max()
     if datatype.startswith("cf64"):   # fp64 arithmetic, fp32 storage
         f32 = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_DB20_F32)
         assert f32.dtype == np.float32 and np.abs(f32 - got[:-1]).max() <= 2e-5
