@@ -101,3 +101,51 @@ def test_sharded_waterfall_and_welch_gloo(world, total):
     same, psd_err = q.get(timeout=10)
     assert same, "gathered spectrogram differs from the single-process oracle"
     assert psd_err < 1e-12
+
+
+# ---- bench.py's own launch behaviour (no GPU needed: the checks sit in front of the first HIP call) ----------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(extra_env, *args):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          timeout=300, env=env)
+
+
+def test_bench_gpus_n_without_a_launcher_reports_too_few_gpus():
+    """`python bench.py --gpus 8` on a node with fewer GPUs: one JSON error line, non-zero status, no launch."""
+    import json
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has the GPUs")
+    r = _run_bench({}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 2
+    assert "shows" in json.loads(r.stdout.strip().splitlines()[-1])["error"]
+
+
+def test_bench_gpus_n_without_a_launcher_starts_torchrun_as_a_child():
+    """Started without torch.distributed.run, bench.py starts `python -m torch.distributed.run --nproc-per-node N
+    bench.py ...` itself -- as a child, before anything touches the GPU -- and leaves with the child's status.  Here
+    (no GPU) the ranks fail at their first GPU call; what is checked is that the child WAS the launcher and that its
+    failure is relayed, not swallowed."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = _run_bench({"SPEC_BENCH_REHEARSE": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0", "--log2-samples", "16")
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+    assert "--master-addr 127.0.0.1" in r.stderr
+    assert r.returncode != 0                       # the ranks could not get a GPU: relayed
+
+
+def test_bench_gather_watchdog_leaves_with_a_non_zero_status():
+    """The gather watchdog prints the compute-only headline with a gather error marker and then exits NON-zero
+    (an abandoned gather -- stalled transport, hung GPU -- must not read as a clean run)."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    bail = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "bail")
+    exits = [n for n in ast.walk(bail) if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "_exit"]
+    assert exits and all(isinstance(c.args[0], ast.Constant) and c.args[0].value != 0 for c in exits)
+    assert '"gather"' in ast.get_source_segment(src, bail) and "error" in ast.get_source_segment(src, bail)

@@ -44,9 +44,22 @@ out = {"kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main
        "hbm_read_bytes_per_launch(FETCH_SIZE*1024*2)": fetch, "hbm_write_bytes_per_launch(WRITE_SIZE*1024)": write,
        "hbm_traffic_bytes_per_launch": traffic}
 json.dump(out, open(os.path.join(dst, rnd + "_pmc.json"), "w"), indent=1)
+
+def _stamp(profile):
+    """Where a traffic figure comes from: the commit of the tree the profile was taken on (HEAD when the summary is
+    written -- summarise before committing further kernel changes), the summary file, the date."""
+    import datetime, subprocess
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "--", "spectral_analyzer_amd/csrc"]) != 0
+    except Exception:
+        commit, dirty = "unknown", False
+    return {"commit": commit + ("+uncommitted csrc changes" if dirty else ""), "profile": profile,
+            "date": datetime.date.today().isoformat()}
+
 tp = os.path.join(dst, "pmc_traffic.json")
 t = json.load(open(tp)) if os.path.exists(tp) else {}
-t[workload] = traffic
+t[workload] = {"bytes": traffic, **_stamp("profiles/%s_pmc.json" % rnd)}
 json.dump(t, open(tp, "w"), indent=1)
 with open(os.path.join(dst, rnd + "_summary.md"), "w") as f:
     f.write("# %s -- rocprofv3 summary (%s)\n\n" % (rnd, workload))

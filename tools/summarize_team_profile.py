@@ -46,9 +46,22 @@ out = {"kernel": main["Name"], "calls": int(main["Calls"]), "avg_ns": float(main
        "hbm_side_read_bytes_per_step(FETCH_SIZE*1024*2)": step_fetch, "hbm_side_write_bytes_per_step(WRITE_SIZE*1024)": step_write,
        "hbm_side_traffic_bytes_per_step": step_fetch + step_write, "kernels": per_kernel, "bench_line_under_profiler": bench}
 json.dump(out, open(os.path.join(dst, "%s_%s_pmc.json" % (rnd, workload)), "w"), indent=1)
+
+def _stamp(profile):
+    """Where a traffic figure comes from: the commit of the tree the profile was taken on (HEAD when the summary is
+    written -- summarise before committing further kernel changes), the summary file, the date."""
+    import datetime, subprocess
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = subprocess.call(["git", "-C", root, "diff", "--quiet", "--", "spectral_analyzer_amd/csrc"]) != 0
+    except Exception:
+        commit, dirty = "unknown", False
+    return {"commit": commit + ("+uncommitted csrc changes" if dirty else ""), "profile": profile,
+            "date": datetime.date.today().isoformat()}
+
 tp = os.path.join(dst, "pmc_traffic.json")
 t = json.load(open(tp)) if os.path.exists(tp) else {}
-t[workload] = step_fetch + step_write
+t[workload] = {"bytes": step_fetch + step_write, **_stamp("profiles/%s_%s_pmc.json" % (rnd, workload))}
 json.dump(t, open(tp, "w"), indent=1)
 d = mean[main["Name"]]
 with open(os.path.join(dst, "%s_%s_summary.md" % (rnd, workload)), "w") as f:
