@@ -185,6 +185,42 @@ spec_status spec_waterfall(spec_ctx *ctx, const void *iq, int iq_on_device, uint
                            uint64_t n_lines, spec_window window, spec_out_fmt out_fmt,
                            double eof_fill, void *out, int out_on_device);
 
+/* ---- one waterfall across several devices ------------------------ */
+
+/* Lines are independent (MainController.java:982-993 computes every waterfall[t] from its own sample span), so
+ * a long recording shards by time slice: shard r of n takes the contiguous lines [r L / n, (r + 1) L / n) and
+ * reads its own sample span plus the nfft - hop halo it shares with its neighbour -- no input exchange.  The
+ * reference host is ONE process (JavaFxApplication.java:31-54), so the sharding is offered here at the C ABI,
+ * one context (= one device) per shard, not only to multi-process hosts (spectral_analyzer_amd/dist.py).
+ * spec_shard_lines / spec_shard_span are the partition spec_waterfall_multi uses (identical to dist.shard_lines /
+ * dist.shard_span), for callers that place each shard's bytes on its device themselves. */
+void spec_shard_lines(uint64_t n_lines, uint32_t n_shards, uint32_t shard, uint64_t *first_line, uint64_t *end_line);
+/* bytes of the recording, counted from its start_byte, that lines [first_line, end_line) read */
+void spec_shard_span(uint64_t first_line, uint64_t end_line, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                     uint64_t *first_byte, uint64_t *n_bytes);
+
+/* spec_waterfall with the lines sharded over n_ctx contexts, one host thread per context, all devices at work at
+ * once.  L = min(n_lines, spec_count_lines(n_bytes, start_byte, ...)) lines are computed, shard r by ctx[r]; lines
+ * past the end of the recording are eof_fill (MC:994-998), as in spec_waterfall.
+ *   iq_on_device == 0: iq[0] is the whole recording in HOST memory (n_bytes long; what a JVM holds: the mapped
+ *       file); every context stages the span of its own shard through its own pipeline.  iq[1 ...] are not read.
+ *   iq_on_device != 0: iq[r] is DEVICE memory of ctx[r]'s device holding exactly shard r's span: byte 0 of iq[r]
+ *       is byte start_byte + first_byte_r of the recording (spec_shard_span of spec_shard_lines(L, n_ctx, r)).
+ *   out_on_device == 0: `out` is the HOST tile n_lines x nfft; every context copies its own rows there.
+ *   out_on_device != 0: `out` is device memory of ctx[0]'s device (the consumer).  ctx[0] computes its rows in
+ *       place; every other context computes its range in n_chunks pieces (0 = 8) and sends each finished piece
+ *       straight into the consumer's rows with hipMemcpyPeerAsync on a second stream behind an event recorded
+ *       after that piece's kernels -- the transfer of piece j overlaps the kernels of piece j + 1 (over xGMI every
+ *       peer has its own link to the consumer) -- through a two-slot buffer, so no context holds a second tile.
+ * The call returns when the whole tile is in `out`.  Contexts may share a device (then they share its kernels'
+ * time -- and the persistent large-N kernel of "large_team", which wants a whole device to itself, falls back to its
+ * two-launch form after a bounded wait: give every context its own device); the same context may not appear twice.  On failure the first failing shard's status is returned and its
+ * text is spec_last_error(ctx[0]). */
+spec_status spec_waterfall_multi(spec_ctx *const *ctx, uint32_t n_ctx, const void *const *iq, int iq_on_device,
+                                 uint64_t n_bytes, uint64_t start_byte, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                                 uint64_t n_lines, spec_window window, spec_out_fmt out_fmt, double eof_fill,
+                                 void *out, int out_on_device, uint32_t n_chunks);
+
 /* ---- recordings on disk (SURVEY 8f "next" #3) ------------------------------ */
 
 /* Replaces the mapping step of SigMfHelper.load (sigmf/SigMfHelper.java:69-94): the reference maps at

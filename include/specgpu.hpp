@@ -41,6 +41,22 @@ public:
         return out;
     }
 
+    // the same loop sharded over several services (one per device), host buffer in, host tile out: spec_waterfall_multi
+    static std::vector<float> computeWaterfallMulti(const std::vector<const SpectralService *> &services, const void *buffer,
+                                                    uint64_t capacity, uint64_t startByte, uint32_t nfft, uint32_t hop,
+                                                    uint64_t nLines, const std::string &datatype,
+                                                    spec_window window = SPEC_WIN_RECT) {
+        if (services.empty()) throw std::invalid_argument("no services");
+        std::vector<spec_ctx *> ctx;
+        for (const SpectralService *s : services) ctx.push_back(s->ctx_);
+        std::vector<float> out(nLines * nfft);
+        const void *iq[1] = {buffer};
+        check(spec_waterfall_multi(ctx.data(), (uint32_t)ctx.size(), iq, 0, capacity, startByte,
+                                   spec_dtype_from_sigmf(datatype.c_str()), nfft, hop, nLines, window, SPEC_OUT_DB20_F32,
+                                   -150.0, out.data(), 0, 0), ctx[0]);
+        return out;
+    }
+
     // PowerSpectralDensity.calculatePsdWelch(data, fs, nfft) (AnalysisDialogController.java:308-312):
     // returns {freq, psd}.  psd is in dB/Hz (10 log10(P + 1e-20)) by default: the caller adds a dB offset to it
     // (AnalysisDialogController.java:319-328), labels clicked values "dB" (:612, :626), takes the SNR as their

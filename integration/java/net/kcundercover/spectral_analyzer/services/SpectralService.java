@@ -66,6 +66,25 @@ public class SpectralService implements AutoCloseable {
         return tile;
     }
 
+    /**
+     * {@link #computeWaterfall} with the lines sharded over several services, one per GPU of the node
+     * ({@code new SpectralService(0) ... new SpectralService(7)}): lines are independent
+     * (MainController.updateDisplay computes every {@code waterfall[t]} from its own span), so shard
+     * {@code r} of {@code n} takes the contiguous lines {@code [r L / n, (r + 1) L / n)}; inside the
+     * library every device stages and transforms its own span on a host thread of its own and copies
+     * its rows into {@code tile}.  {@code services[0]} reports failures.  One JVM, many GPUs.
+     */
+    public static float[] computeWaterfallMulti(SpectralService[] services, ByteBuffer buffer, long startByte,
+                                                int nfft, int hop, int nLines, String datatype, int window) {
+        long[] handles = new long[services.length];
+        for (int i = 0; i < services.length; i++) {
+            handles[i] = services[i].handle;
+        }
+        float[] tile = new float[Math.multiplyExact(nLines, nfft)];
+        nativeWaterfallMulti(handles, buffer, startByte, nativeDtype(datatype), nfft, hop, nLines, window, -150.0, tile);
+        return tile;
+    }
+
     /** Welch PSD of the samples from {@code startByte}; returns {frequency axis, psd}. */
     public double[][] welchPsd(ByteBuffer buffer, long startByte, String datatype, double sampleRate,
                                int nfft, int hop, int segments, int window, int scaling, boolean decibel) {
@@ -200,6 +219,9 @@ public class SpectralService implements AutoCloseable {
                                                        String datatype, boolean bigEndian, double[] out);
     private static native void nativeWaterfall(long handle, ByteBuffer buffer, long startByte, int dtype, int nfft,
                                                int hop, long nLines, int window, double eofFill, float[] out);
+    private static native void nativeWaterfallMulti(long[] handles, ByteBuffer buffer, long startByte, int dtype, int nfft,
+                                                    int hop, long nLines, int window, double eofFill, float[] out);
+
     private static native void nativeWelch(long handle, ByteBuffer buffer, long startByte, int dtype, int nfft,
                                            int hop, int segments, int window, int scaling, double sampleRate,
                                            boolean decibel, double[] freq, float[] psd);

@@ -91,6 +91,33 @@ JNIEXPORT void JNICALL JNI_FN(nativeWaterfall)(JNIEnv *env, jclass k, jlong h, j
     if (st != SPEC_OK) throw_status(env, ctx, st);
 }
 
+/* the same loop sharded over several contexts, one per device: host buffer in, host tile out */
+JNIEXPORT void JNICALL JNI_FN(nativeWaterfallMulti)(JNIEnv *env, jclass k, jlongArray handles, jobject buffer,
+                                                     jlong startByte, jint dtype, jint nfft, jint hop, jlong nLines,
+                                                     jint window, jdouble eofFill, jfloatArray out) {
+    (void)k;
+    const jsize n = (*env)->GetArrayLength(env, handles);
+    if (n < 1 || n > 64) { throw_shim(env, "computeWaterfallMulti: 1 ... 64 services"); return; }
+    void *base = (*env)->GetDirectBufferAddress(env, buffer);
+    jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
+    if (!base || cap < 0) { throw_shim(env, "computeWaterfallMulti: not a direct buffer"); return; }
+    if (nfft < 0 || nLines < 0 || (jlong)(*env)->GetArrayLength(env, out) < nLines * (jlong)nfft) {
+        throw_shim(env, "computeWaterfallMulti: out is shorter than nLines * nfft");
+        return;
+    }
+    spec_ctx *ctx[64];
+    jlong *h = (*env)->GetLongArrayElements(env, handles, NULL);
+    for (jsize i = 0; i < n; ++i) ctx[i] = (spec_ctx *)(intptr_t)h[i];
+    (*env)->ReleaseLongArrayElements(env, handles, h, JNI_ABORT);
+    const void *iq[1] = {base};
+    jfloat *o = (*env)->GetFloatArrayElements(env, out, NULL);
+    spec_status st = spec_waterfall_multi(ctx, (uint32_t)n, iq, 0, (uint64_t)cap, (uint64_t)startByte, (spec_dtype)dtype,
+                                          (uint32_t)nfft, (uint32_t)hop, (uint64_t)nLines, (spec_window)window,
+                                          SPEC_OUT_DB20_F32, eofFill, o, 0, 0);
+    (*env)->ReleaseFloatArrayElements(env, out, o, st == SPEC_OK ? 0 : JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx[0], st);
+}
+
 /* PowerSpectralDensity.calculatePsdWelch call site (ADC:308-312): freq[nfft], psd[nfft] */
 JNIEXPORT void JNICALL JNI_FN(nativeWelch)(JNIEnv *env, jclass k, jlong h, jobject buffer, jlong startByte,
                                             jint dtype, jint nfft, jint hop, jint nSeg, jint window, jint scaling,

@@ -46,6 +46,10 @@ SIGNATURES = {
     "spec_count_lines": (_u64, [_u64, _u64, _i32, _u32, _u32]),
     "spec_compute_magnitudes": (_i32, [_vp, _vp, _u64, C.c_int64, _u32, _cp, _i32, _vp]),
     "spec_waterfall": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u64, _i32, _i32, _dbl, _vp, _i32]),
+    "spec_shard_lines": (None, [_u64, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
+    "spec_shard_span": (None, [_u64, _u64, _i32, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
+    "spec_waterfall_multi": (_i32, [C.POINTER(_vp), _u32, C.POINTER(_vp), _i32, _u64, _u64, _i32, _u32, _u32, _u64, _i32,
+                                    _i32, _dbl, _vp, _i32, _u32]),
     "spec_open_recording": (_i32, [_vp, _cp, _u64, C.POINTER(_vp)]),
     "spec_recording_bytes": (_u64, [_vp]),
     "spec_close_recording": (None, [_vp]),

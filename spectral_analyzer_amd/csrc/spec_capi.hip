@@ -54,6 +54,11 @@ struct spec_ctx {
     // each copied to the device by an asynchronous (truly overlapped) transfer
     void *pin_in = nullptr;    size_t pin_in_bytes = 0;
     hipEvent_t ev_pin[2] = {nullptr, nullptr};  // slot's host->device copy has left the pinned buffer
+    // spec_waterfall_multi: a peer context's two-slot buffer of finished pieces, its copy stream and the events
+    // "piece computed" / "piece has left the slot"
+    void *multi_buf = nullptr; size_t multi_buf_bytes = 0;
+    hipStream_t s_peer = nullptr;
+    hipEvent_t ev_mdone[2] = {nullptr, nullptr}, ev_mcopied[2] = {nullptr, nullptr};
     void *team_scratch = nullptr; size_t team_scratch_bytes = 0;  // spec_k_team.hip: ring slots of every team
     void *team_sync = nullptr;    size_t team_sync_bytes = 0;     //                   tickets, ring counters, abort word    // spec_welch_psd_planar_f64: interleaved copy of the burst
     // tuning / testing knobs (spec_set_option)
@@ -274,6 +279,12 @@ void spec_destroy(spec_ctx *c) {
     (void)hipFree(c->team_scratch);
     (void)hipFree(c->team_sync);
     (void)hipFree(c->sel_dev);
+    (void)hipFree(c->multi_buf);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_mdone[i]) (void)hipEventDestroy(c->ev_mdone[i]);
+        if (c->ev_mcopied[i]) (void)hipEventDestroy(c->ev_mcopied[i]);
+    }
+    if (c->s_peer) (void)hipStreamDestroy(c->s_peer);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
         if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
@@ -912,6 +923,162 @@ spec_status spec_waterfall(spec_ctx *c, const void *iq, int iq_on_device, uint64
                           out_on_device, nullptr, 0);
 }
 
+// ---- one waterfall across several devices --------------------------------------------------
+void spec_shard_lines(uint64_t n_lines, uint32_t n_shards, uint32_t shard, uint64_t *first_line, uint64_t *end_line) {
+    uint64_t a = 0, b = 0;
+    if (n_shards && shard < n_shards) {  // r L / n without overflowing 64 bits
+        a = (uint64_t)(((unsigned __int128)n_lines * shard) / n_shards);
+        b = (uint64_t)(((unsigned __int128)n_lines * (shard + 1)) / n_shards);
+    }
+    if (first_line) *first_line = a;
+    if (end_line) *end_line = b;
+}
+
+void spec_shard_span(uint64_t first_line, uint64_t end_line, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                     uint64_t *first_byte, uint64_t *n_bytes) {
+    const uint64_t bps = spec_bytes_per_sample(dt);
+    if (first_byte) *first_byte = first_line * hop * bps;
+    if (n_bytes) *n_bytes = end_line > first_line ? ((end_line - first_line - 1) * hop + nfft) * bps : 0;
+}
+
+// shard [l0, l1) of a multi-device waterfall on context c.  `src` / `src_bytes` / `src_off`: the buffer this
+// context reads (the whole host recording, or its own device span) and the byte its first line starts at.
+static spec_status multi_shard(spec_ctx *c, spec_ctx *root, bool is_root, const void *src, int src_on_device,
+                               uint64_t src_bytes, uint64_t src_off, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                               uint64_t l0, uint64_t l1, spec_window window, spec_out_fmt out_fmt, void *out,
+                               int out_on_device, uint32_t n_chunks) {
+    if (l1 <= l0) return SPEC_OK;
+    const uint64_t bps = spec_bytes_per_sample(dt), out_esz = out_fmt >= SPEC_OUT_DB20_F64 ? 8 : 4;
+    const uint64_t row_bytes = (uint64_t)nfft * out_esz;
+    uint8_t *const out_rows = static_cast<uint8_t *>(out) + l0 * row_bytes;
+    if (!out_on_device || is_root) {  // host tile: own rows, own copy-out; consumer: in place
+        spec_status st = waterfall_impl(c, src, src_on_device, src_bytes, src_off, dt, nfft, hop, l1 - l0, window, out_fmt,
+                                        -150.0, out_rows, out_on_device, nullptr, 0);
+        if (st != SPEC_OK) return st;
+        return out_on_device ? spec_sync(c) : SPEC_OK;
+    }
+    // a peer of a device-resident tile: pieces through a two-slot buffer, each sent behind its own kernels
+    Enter g(c);
+    if (n_chunks == 0) n_chunks = 8;
+    if ((uint64_t)n_chunks > l1 - l0) n_chunks = (uint32_t)(l1 - l0);
+    const uint64_t per = (l1 - l0 + n_chunks - 1) / n_chunks;  // lines per piece (the last one may be shorter)
+    const uint64_t slot_bytes = (per * row_bytes + 255) & ~255ull;
+    spec_status st = grow(c, &c->multi_buf, &c->multi_buf_bytes, 2 * slot_bytes);
+    if (st != SPEC_OK) return st;
+    if (!c->s_peer) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->s_peer, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mdone[i], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mcopied[i], hipEventDisableTiming));
+        }
+    }
+    if (c->device != root->device) {  // direct xGMI writes where the platform allows them; staged by the runtime otherwise
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, c->device, root->device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    }
+    uint32_t j = 0;
+    for (uint64_t a = l0; a < l1; a += per, ++j) {
+        const uint64_t b = a + per < l1 ? a + per : l1;
+        const int slot = (int)(j & 1u);
+        uint8_t *buf = static_cast<uint8_t *>(c->multi_buf) + slot * slot_bytes;
+        if (j >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_mcopied[slot], 0));  // piece j - 2 has left the slot
+        st = waterfall_impl(c, src, src_on_device, src_bytes, src_off + (a - l0) * hop * bps, dt, nfft, hop, b - a, window,
+                            out_fmt, -150.0, buf, 1, nullptr, 0);
+        if (st != SPEC_OK) break;
+        HIP_TRY(c, hipEventRecord(c->ev_mdone[slot], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->s_peer, c->ev_mdone[slot], 0));
+        HIP_TRY(c, hipMemcpyPeerAsync(static_cast<uint8_t *>(out) + a * row_bytes, root->device, buf, c->device,
+                                      (b - a) * row_bytes, c->s_peer));
+        HIP_TRY(c, hipEventRecord(c->ev_mcopied[slot], c->s_peer));
+    }
+    const hipError_t e1 = hipStreamSynchronize(c->s_peer), e2 = hipStreamSynchronize(c->stream);
+    if (st != SPEC_OK) return st;
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        return fail(c, SPEC_EDEVICE, "peer copy: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return SPEC_OK;
+}
+
+spec_status spec_waterfall_multi(spec_ctx *const *ctx, uint32_t n_ctx, const void *const *iq, int iq_on_device,
+                                 uint64_t n_bytes, uint64_t start_byte, spec_dtype dt, uint32_t nfft, uint32_t hop,
+                                 uint64_t n_lines, spec_window window, spec_out_fmt out_fmt, double eof_fill, void *out,
+                                 int out_on_device, uint32_t n_chunks) {
+    if (!ctx || n_ctx == 0 || !ctx[0]) return SPEC_EINVAL;
+    spec_ctx *root = ctx[0];
+    if (n_ctx > 64) return fail(root, SPEC_EINVAL, "spec_waterfall_multi: %u contexts (at most 64)", n_ctx);
+    for (uint32_t r = 0; r < n_ctx; ++r) {
+        if (!ctx[r]) return fail(root, SPEC_EINVAL, "spec_waterfall_multi: context %u is NULL", r);
+        for (uint32_t q = 0; q < r; ++q)
+            if (ctx[q] == ctx[r]) return fail(root, SPEC_EINVAL, "spec_waterfall_multi: context %u appears twice", r);
+    }
+    if (!iq || (!iq_on_device && !iq[0])) return fail(root, SPEC_EINVAL, "null buffer");
+    int log2n = 0;  // device shards: an empty shard (fewer lines than contexts) has no buffer, checked per shard below
+    spec_status st = check_common(root, iq_on_device ? static_cast<const void *>(iq) : iq[0], out, dt, nfft, hop, window, &log2n);
+    if (st != SPEC_OK) return st;
+    if (out_fmt < SPEC_OUT_DB20_F32 || out_fmt > SPEC_OUT_POW_F64) return fail(root, SPEC_EINVAL, "bad out_fmt %d", out_fmt);
+    if (n_lines == 0) return SPEC_OK;
+    const uint64_t out_esz = out_fmt >= SPEC_OUT_DB20_F64 ? 8 : 4;
+    {
+        uint64_t tile_bytes = 0;
+        if (!mul_add_u64(n_lines, (uint64_t)nfft * out_esz, 0, &tile_bytes))
+            return fail(root, SPEC_ERANGE, "%llu lines of %u bins do not fit a 64-bit byte count", (unsigned long long)n_lines, nfft);
+    }
+    uint64_t n_valid = spec_count_lines(n_bytes, start_byte, dt, nfft, hop);  // MainController.java:987
+    if (n_valid > n_lines) n_valid = n_lines;
+    if (iq_on_device)
+        for (uint32_t r = 0; r < n_ctx; ++r) {
+            uint64_t a, b;
+            spec_shard_lines(n_valid, n_ctx, r, &a, &b);
+            if (b > a && !iq[r]) return fail(root, SPEC_EINVAL, "spec_waterfall_multi: shard %u has lines but no buffer", r);
+        }
+    std::vector<spec_status> status(n_ctx, SPEC_OK);
+    auto run = [&](uint32_t r) {
+        uint64_t l0, l1, first = 0, span = 0;
+        spec_shard_lines(n_valid, n_ctx, r, &l0, &l1);
+        spec_shard_span(l0, l1, dt, nfft, hop, &first, &span);
+        if (iq_on_device)  // the shard's own span: byte 0 of iq[r] is the first byte of line l0
+            status[r] = multi_shard(ctx[r], root, r == 0, iq[r], 1, span, 0, dt, nfft, hop, l0, l1, window, out_fmt, out,
+                                    out_on_device, n_chunks);
+        else
+            status[r] = multi_shard(ctx[r], root, r == 0, iq[0], 0, n_bytes, start_byte + first, dt, nfft, hop, l0, l1, window,
+                                    out_fmt, out, out_on_device, n_chunks);
+    };
+    std::vector<std::thread> th;
+    for (uint32_t r = 1; r < n_ctx; ++r) {
+        try { th.emplace_back(run, r); }
+        catch (...) { run(r); }  // no thread to be had: this shard runs here, without the overlap
+    }
+    run(0);
+    for (auto &t : th) t.join();
+    for (uint32_t r = 0; r < n_ctx; ++r)
+        if (status[r] != SPEC_OK) {
+            if (r) {
+                std::string msg;
+                { std::lock_guard<std::recursive_mutex> lk(ctx[r]->mu); msg = ctx[r]->err; }
+                return fail(root, status[r], "shard %u of %u: %s", r, n_ctx, msg.c_str());
+            }
+            return status[r];
+        }
+    if (n_valid < n_lines) {  // MC:994-998
+        const uint64_t n = (n_lines - n_valid) * nfft;
+        if (out_on_device) {
+            Enter g(root);
+            hipError_t e = launch_fill(static_cast<uint8_t *>(out) + n_valid * nfft * out_esz, n, eof_fill, out_esz == 8, root->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(root->stream);
+            if (e != hipSuccess) return fail(root, SPEC_EDEVICE, "fill launch: %s", hipGetErrorString(e));
+        } else if (out_esz == 8) {
+            double *p = static_cast<double *>(out) + n_valid * nfft;
+            for (uint64_t i = 0; i < n; ++i) p[i] = eof_fill;
+        } else {
+            float *p = static_cast<float *>(out) + n_valid * nfft;
+            for (uint64_t i = 0; i < n; ++i) p[i] = (float)eof_fill;
+        }
+    }
+    return SPEC_OK;
+}
+
 // ---- recordings on disk (SURVEY 8f "next" #3; SigMfHelper.java:49-94) ---------------------------------
 spec_status spec_open_recording(spec_ctx *c, const char *data_path, uint64_t header_bytes, spec_recording **out) {
     if (!c) return SPEC_EINVAL;
@@ -1158,9 +1325,12 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         if (run > n_seg) run = n_seg;
         // plenty of PSDs (>= two per CU) and whole-workgroup lines: one workgroup walks all segments of a PSD and
         // finishes it itself -- no slabs, no second launch
-        // (a workgroup addresses its span through one buffer descriptor: 32-bit byte range)
+        // (a workgroup addresses its span through one buffer descriptor: 32-bit byte range).  The kernel sums |X|^2 in
+        // fp32 registers over its whole run: bounded to 512 segments here (worst-case 512 eps/2 = 3e-5 relative for a
+        // sum of positive terms, ~1e-6 typical); longer PSDs take the slab form -- runs of <= 64 segments summed in
+        // double by the reduction -- so that the 5e-6 of the parity tests holds for any n_seg
         const bool fused = sub == 1 && c->opt_lines_per_wg <= 0 && !c->opt_welch_two_pass && (uint64_t)n_psd >= 2ull * (uint64_t)c->n_cu &&
-                           ((uint64_t)n_seg - 1) * hop * bps + (uint64_t)nfft * bps < (1ull << 31);
+                           n_seg <= 512 && ((uint64_t)n_seg - 1) * hop * bps + (uint64_t)nfft * bps < (1ull << 31);
         if (fused) run = n_seg;
         const uint32_t wgs = (uint32_t)((n_seg + run * sub - 1) / (run * sub));
         const uint32_t n_slabs = wgs * sub;

@@ -54,6 +54,71 @@ def _host_bytes(buffer) -> np.ndarray:
     return np.ascontiguousarray(a)
 
 
+def shard_lines(n_lines: int, n_shards: int, shard: int) -> Tuple[int, int]:
+    """``spec_shard_lines``: the half-open line range of a shard (the partition of ``compute_waterfall_multi``)."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    L.load().spec_shard_lines(int(n_lines), int(n_shards), int(shard), C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+def shard_span(first_line: int, end_line: int, datatype: str, nfft: int, hop: int) -> Tuple[int, int]:
+    """``spec_shard_span``: (first byte counted from the recording's start byte, byte count) of those lines."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    L.load().spec_shard_span(int(first_line), int(end_line), dtype_from_sigmf(datatype), int(nfft), int(hop),
+                             C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+def compute_waterfall_multi(services, buffer, start_byte: int, nfft: int, datatype: str, n_lines: int,
+                            hop: Optional[int] = None, window: int = L.WIN_RECT, out_fmt: int = L.OUT_DB20_F32,
+                            eof_fill: float = -150.0, out=None, n_bytes: Optional[int] = None, n_chunks: int = 0):
+    """``spec_waterfall_multi``: one waterfall (MC:980-999) with its lines sharded over several ``SpectralService``
+    contexts -- one host thread per context inside the library, no ``torch.distributed``; what a single-process
+    host (the reference is one JVM) uses to drive the GPUs of a node.
+
+    ``buffer``: host bytes of the whole recording (every context stages its own span), or a LIST of CUDA uint8
+    tensors, entry r on ``services[r]``'s device holding exactly shard r's span (``shard_lines`` / ``shard_span``
+    of the first min(n_lines, whole lines in the recording) lines; ``n_bytes`` = the recording's byte count then).
+    ``out``: None / numpy array -> host tile; a CUDA tensor on ``services[0]``'s device -> the peers send their
+    pieces there with ``hipMemcpyPeerAsync`` behind each piece's kernels.  Returns the tile."""
+    lib = L.load()
+    hop = int(nfft if hop is None else hop)
+    dt = dtype_from_sigmf(datatype)
+    np_dt = _OUT_NP[out_fmt]
+    n = len(services)
+    ctxs = (C.c_void_p * n)(*[s._ctx for s in services])
+    keep = None
+    if isinstance(buffer, (list, tuple)):
+        import torch
+        if len(buffer) != n or n_bytes is None:
+            raise ValueError("device input: one tensor per service and n_bytes (the recording's byte count)")
+        for t in buffer:
+            if t is not None and (not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous()):
+                raise ValueError("device buffers must be contiguous CUDA uint8 tensors")
+        bufs = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None for t in buffer])
+        on_dev = 1
+    else:
+        keep = _host_bytes(buffer)
+        bufs = (C.c_void_p * n)(*([C.c_void_p(keep.ctypes.data)] + [None] * (n - 1)))
+        n_bytes, on_dev = keep.size, 0
+    if out is not None and _is_torch(out):
+        import torch
+        t_dt = torch.float32 if np_dt is np.float32 else torch.float64
+        if not out.is_cuda or out.dtype != t_dt or out.numel() < n_lines * nfft or not out.is_contiguous():
+            raise ValueError("out tensor has the wrong dtype/size")
+        res, out_ptr, out_dev = out, out.data_ptr(), 1
+    else:
+        res = np.empty((int(n_lines), int(nfft)), dtype=np_dt) if out is None else out
+        if (not isinstance(res, np.ndarray) or res.dtype != np_dt or res.size < n_lines * nfft or not res.flags.c_contiguous):
+            raise ValueError("out array has the wrong dtype/size")
+        out_ptr, out_dev = res.ctypes.data, 0
+    st = lib.spec_waterfall_multi(ctxs, n, bufs, on_dev, int(n_bytes), int(start_byte), dt, int(nfft), hop, int(n_lines),
+                                  window, out_fmt, float(eof_fill), out_ptr, out_dev, int(n_chunks))
+    del keep
+    services[0]._check(st)
+    return res
+
+
 class SpectralService:
     """GPU-backed drop-in for the reference ``SpectralService`` singleton."""
 

@@ -26,6 +26,7 @@ jlong SS(nativeCreate)(JNIEnv *, jclass, jint, jint);
 void SS(nativeDestroy)(JNIEnv *, jclass, jlong);
 void SS(nativeComputeMagnitudes)(JNIEnv *, jclass, jlong, jobject, jint, jint, jstring, jboolean, jdoubleArray);
 void SS(nativeWaterfall)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, jint, jlong, jint, jdouble, jfloatArray);
+void SS(nativeWaterfallMulti)(JNIEnv *, jclass, jlongArray, jobject, jlong, jint, jint, jint, jlong, jint, jdouble, jfloatArray);
 void SS(nativeWelch)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, jint, jint, jint, jint, jdouble, jboolean,
                      jdoubleArray, jfloatArray);
 void SS(nativeWaterfallRender)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, jint, jint, jint, jint, jdouble,
@@ -104,12 +105,14 @@ static jfloat *f_GetF(JNIEnv *e, jfloatArray a, jboolean *c) { (void)e; return (
 static void f_RelF(JNIEnv *e, jfloatArray a, jfloat *p, jint m) { (void)e; release_elems(a, p, m); }
 static jint *f_GetI(JNIEnv *e, jintArray a, jboolean *c) { (void)e; return (jint *)get_elems(a, c); }
 static void f_RelI(JNIEnv *e, jintArray a, jint *p, jint m) { (void)e; release_elems(a, p, m); }
+static jlong *f_GetL(JNIEnv *e, jlongArray a, jboolean *c) { (void)e; return (jlong *)get_elems(a, c); }
+static void f_RelL(JNIEnv *e, jlongArray a, jlong *p, jint m) { (void)e; release_elems(a, p, m); }
 static void *f_BufAddr(JNIEnv *e, jobject b) { (void)e; return ((fake_obj *)b)->data; }
 static jlong f_BufCap(JNIEnv *e, jobject b) { (void)e; return ((fake_obj *)b)->data ? ((fake_obj *)b)->cap : -1; }
 
 static const struct JNINativeInterface_ table = {
     f_FindClass, f_ThrowNew, f_GetStringUTFChars, f_ReleaseStringUTFChars, f_GetArrayLength,
-    f_GetD, f_RelD, f_GetF, f_RelF, f_GetI, f_RelI, f_BufAddr, f_BufCap,
+    f_GetD, f_RelD, f_GetF, f_RelF, f_GetI, f_RelI, f_GetL, f_RelL, f_BufAddr, f_BufCap,
 };
 static JNIEnv env_value = &table;
 static JNIEnv *env = &env_value;
@@ -186,6 +189,25 @@ int main(void) {
     fake_obj a_tile_short = mk_array(tile, LINES * NFFT - 1, 4);
     SS(nativeWaterfall)(env, NULL, h, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile_short);
     expect_throw("java/lang/IllegalArgumentException", "shorter than nLines", "short tile");
+
+    /* the same loop sharded over three services (here: three contexts on the one GPU) -- bit for bit the single-context tile */
+    {
+        jlong hs[3] = {h, SS(nativeCreate)(env, NULL, 0, 0), SS(nativeCreate)(env, NULL, 0, 0)};
+        expect_clean("nativeCreate x2");
+        fake_obj a_hs = mk_array(hs, 3, 8);
+        memset(tile, 0, (size_t)LINES * NFFT * 4);
+        SS(nativeWaterfallMulti)(env, NULL, &a_hs, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile);
+        expect_clean("computeWaterfallMulti");
+        CHECK(memcmp(tile, tile_ref, (size_t)LINES * NFFT * 4) == 0, "computeWaterfallMulti differs from the single-context tile");
+        SS(nativeWaterfallMulti)(env, NULL, &a_hs, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile_short);
+        expect_throw("java/lang/IllegalArgumentException", "shorter than nLines", "short tile (multi)");
+        jlong twice[2] = {h, h};
+        fake_obj a_twice = mk_array(twice, 2, 8);
+        SS(nativeWaterfallMulti)(env, NULL, &a_twice, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile);
+        expect_throw("java/lang/IllegalArgumentException", "appears twice", "same service twice");
+        SS(nativeDestroy)(env, NULL, hs[1]);
+        SS(nativeDestroy)(env, NULL, hs[2]);
+    }
 
     /* the same recording as a FILE with a 100-byte header, opened by path (SigMfHelper.java:69-94 replaced) */
     {

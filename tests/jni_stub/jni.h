@@ -30,6 +30,7 @@ typedef jobject jarray;
 typedef jarray jdoubleArray;
 typedef jarray jfloatArray;
 typedef jarray jintArray;
+typedef jarray jlongArray;
 
 struct JNINativeInterface_;
 typedef const struct JNINativeInterface_ *JNIEnv;
@@ -46,6 +47,8 @@ struct JNINativeInterface_ {
     void (*ReleaseFloatArrayElements)(JNIEnv *env, jfloatArray array, jfloat *elems, jint mode);
     jint *(*GetIntArrayElements)(JNIEnv *env, jintArray array, jboolean *isCopy);
     void (*ReleaseIntArrayElements)(JNIEnv *env, jintArray array, jint *elems, jint mode);
+    jlong *(*GetLongArrayElements)(JNIEnv *env, jlongArray array, jboolean *isCopy);
+    void (*ReleaseLongArrayElements)(JNIEnv *env, jlongArray array, jlong *elems, jint mode);
     void *(*GetDirectBufferAddress)(JNIEnv *env, jobject buf);
     jlong (*GetDirectBufferCapacity)(JNIEnv *env, jobject buf);
 };

@@ -655,3 +655,51 @@ def test_waterfall_render_fused_device_resident(svc, oracle):
         svc.set_option("render_fused", 1)
     torch.cuda.synchronize()
     assert img.is_cuda and torch.equal(img, ref)
+
+
+# ---- spec_waterfall_multi: one waterfall over several contexts (SURVEY 8e at the C ABI) ------------------------
+@pytest.mark.parametrize("datatype,nfft,hop,n_lines,fmt", [("cf32_le", 4096, 2048, 1001, sa.OUT_DB20_F32),
+                                                           ("ci16_le", 1024, 1024, 77, sa.OUT_DB20_F32),
+                                                           ("cf64_le", 16384, 8192, 60, sa.OUT_DB20_F64),   # < 64 lines: the two-launch four-step path in every context (three persistent team kernels cannot share ONE device)
+                                                           ("cu8", 256, 100, 2, sa.OUT_POW_F32)])
+def test_waterfall_multi_equals_the_single_context_tile(svc, oracle, datatype, nfft, hop, n_lines, fmt):
+    """Three contexts (all on device 0 on the one-GPU box; one per GPU on a node), one host thread each inside the
+    library, contiguous line ranges with the nfft - hop halo exactly as dist.shard_lines / shard_span: the tile is the
+    single-context tile BIT FOR BIT -- host buffer -> host tile (what the JVM host uses), and device-resident
+    shards -> a tile on the consumer's device, the peers' pieces sent with hipMemcpyPeerAsync behind their kernels.
+    Lines past the end are -150 (MC:994-998); a shard may be empty (fewer lines than contexts)."""
+    import torch
+    from spectral_analyzer_amd import dist as sd
+    bps = oracle.bytes_per_sample(datatype)
+    iq = oracle.synth_iq(datatype, 5, 0, (n_lines - 1) * hop + nfft)
+    extra = 3                                                               # lines past the end of the recording
+    one = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + extra, hop=hop, out_fmt=fmt)
+    peers = [sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream) for _ in range(2)]
+    services = [svc] + peers
+    try:
+        host = sa.compute_waterfall_multi(services, iq, 0, nfft, datatype, n_lines + extra, hop=hop, out_fmt=fmt)
+        assert host.dtype == one.dtype and np.array_equal(host, one)
+        assert np.all(host[n_lines:] == -150.0)
+        # device-resident shards -> device tile on services[0]'s device, in 5 pieces per peer
+        shards = []
+        for r in range(3):
+            l0, l1 = sa.shard_lines(n_lines, 3, r)
+            assert (l0, l1) == sd.shard_lines(n_lines, 3, r)
+            first, nb = sa.shard_span(l0, l1, datatype, nfft, hop)
+            assert (first, nb) == tuple(bps * x for x in sd.shard_span(l0, l1, nfft, hop))
+            shards.append(torch.from_numpy(iq[first:first + nb].copy()).cuda() if nb else None)
+        out = torch.full((n_lines + extra, nfft), float("nan"), dtype=torch.from_numpy(one[:1]).dtype, device="cuda")
+        got = sa.compute_waterfall_multi(services, shards, 0, nfft, datatype, n_lines + extra, hop=hop, out_fmt=fmt, out=out,
+                                         n_bytes=iq.size, n_chunks=5)
+        assert got is out and np.array_equal(out.cpu().numpy(), one)
+        # host buffer -> device tile (the peers stage their spans, then send)
+        out.fill_(float("nan"))
+        sa.compute_waterfall_multi(services, iq, 0, nfft, datatype, n_lines + extra, hop=hop, out_fmt=fmt, out=out)
+        assert np.array_equal(out.cpu().numpy(), one)
+        with pytest.raises(ValueError):                                     # the same context twice
+            sa.compute_waterfall_multi([svc, svc], iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=fmt)
+        with pytest.raises(ValueError):                                     # the reference's error behaviour is kept
+            sa.compute_waterfall_multi(services, iq, 0, nfft - 1, datatype, n_lines, hop=hop, out_fmt=fmt)
+    finally:
+        for p in peers:
+            p.close()
