@@ -114,16 +114,19 @@ void *spec_stream(const spec_ctx *ctx);
 /* Tuning / testing knobs (not needed for normal use):
  *   "force_generic" = 1  route every request through the generic (scalar-math) kernels
  *   "lines_per_wg"  = n  consecutive lines (Welch: segments) walked by one sub-line / workgroup (0 = automatic)
- *   "large_chunk_mb" = m scratch size of the two-launch four-step path (nfft >= 32768; default 1024 MiB)
+ *   "large_chunk_mb" = m scratch size of the two-launch four-step path ("large_team" = 0 and calls of < 64 lines;
+ *                     default 1024 MiB)
  *   "welch_two_pass" = 1 always sum Welch partial slabs in a second launch (default 0: batches of >= two PSDs per CU
  *                     with nfft >= 2048 are finished by the workgroup that walked the PSD's segments)
  *   "rec_pread" = 0 | 1   recordings opened by path: 0 (default) stage from the library's own mapping of the file,
  *                     1 = pread into a pinned two-slot ring (one more host copy; for files that cannot be mapped)
- *   "large_team" = 0 | 1 | 2   lines longer than the LDS holds (fp32 nfft >= 32768, fp64 nfft >= 16384): 1 (default)
+ *   "large_team" = 0 | 1 | 2 | 3   lines longer than the LDS holds (fp32 nfft >= 32768, fp64 nfft >= 16384): 1 (default)
  *                     = one persistent launch that keeps the intermediate in each XCD's L2, for calls of >= 64 lines,
- *                     with the two-launch path behind it as a guarded fall-back; 0 = two-launch path only; 2 = the
- *                     persistent launch for any number of lines and no fall-back (the call then waits for the
- *                     kernel and returns SPEC_EDEVICE if one of its bounded waits timed out)
+ *                     with ONE guarded launch of a self-contained fall-back behind it (it runs only if a bounded wait of
+ *                     the persistent launch timed out: a shared GPU); 0 = two-launch path only; 2 = the persistent
+ *                     launch for any number of lines and no fall-back (the call then waits for the kernel and returns
+ *                     SPEC_EDEVICE if one of its bounded waits timed out); 3 (tests) = the fall-back alone, as if the
+ *                     persistent launch had timed out
  *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 2: the slots share the
  *                     XCD's 4 MiB L2 with the input and output streams; 3 measured 5 % slower, 4 20 %)
  *   "large_wg" = 256 | 512  threads per workgroup of the persistent launch (default 512: one workgroup per CU, 16-bin =

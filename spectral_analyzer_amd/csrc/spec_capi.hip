@@ -315,7 +315,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "rec_pread")) c->opt_rec_pread = value != 0;
     else if (!strcmp(key, "welch_two_pass")) c->opt_welch_two_pass = value != 0;
-    else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 1 ? 1 : (value > 4 ? 4 : value);
     else if (!strcmp(key, "large_wg")) c->opt_large_wg = value == 256 ? 256 : (value == 1024 ? 1024 : 512);
     else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
@@ -494,10 +494,10 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         if ((st = get_twiddles(c, l2, f64, &tw2)) != SPEC_OK) return st;
         const size_t per_line = large_scratch_bytes_per_line(log2n, f64);
         // One persistent launch with the intermediate kept in each XCD's L2 (spec_k_team.hip); behind it, unless
-        // "large_team" = 2, the two-launch path as guarded kernels that run only if a bounded wait of the team
-        // kernel timed out (grid not co-resident: a shared GPU)
-        const uint32_t *run_if = nullptr;
-        const bool team = c->opt_large_team == 2 || (c->opt_large_team == 1 && n_lines >= 64);
+        // "large_team" = 2, ONE guarded launch of the self-contained fall-back (spec_k_large.hip large_solo_kernel) that
+        // runs only if a bounded wait of the team kernel timed out (grid not co-resident: a shared GPU).
+        // "large_team" = 3 (tests): the team kernel is skipped and the abort word set, so the fall-back does the work.
+        const bool team = c->opt_large_team >= 2 || (c->opt_large_team == 1 && n_lines >= 64);
         if (team) {
             uint32_t teams_max = 0;
             const uint32_t ring = (uint32_t)c->opt_large_ring;
@@ -506,44 +506,48 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team query: %s", hipGetErrorString(e));
             if ((st = grow(c, &c->team_scratch, &c->team_scratch_bytes, (size_t)(teams_max ? teams_max : 1) * ring * per_line)) != SPEC_OK) return st;
             if ((st = grow(c, &c->team_sync, &c->team_sync_bytes, large_team_sync_bytes())) != SPEC_OK) return st;
-        }
-        for (uint64_t done = 0; team && done < n_lines;) {
-            const uint64_t nl = n_lines - done < 0x40000000ull ? n_lines - done : 0x40000000ull;  // 32-bit line index
-            uint32_t teams_max = 0;
-            HIP_TRY(c, hipMemsetAsync(c->team_sync, 0, large_team_sync_bytes(), c->stream));
-            a.n_lines = nl;
-            a.iq = d_first + done * (uint64_t)hop * a.bps;
-            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
-            hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, c->team_scratch, (uint32_t)c->opt_large_ring,
-                                               static_cast<uint32_t *>(c->team_sync), c->n_cu, &teams_max, false, c->stream,
-                                               (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
-            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team launch: %s", hipGetErrorString(e));
-            done += nl;
+            // the fall-back's intermediates: one line per workgroup, one workgroup per CU (256 MiB for 65536-point fp64
+            // lines; round 2 kept a 1 GiB chunk scratch for the same purpose)
+            const uint32_t solo_grid = (uint32_t)c->n_cu;
+            if (c->opt_large_team != 2 && (st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)solo_grid * per_line)) != SPEC_OK) return st;
+            for (uint64_t done = 0; done < n_lines;) {
+                const uint64_t nl = n_lines - done < 0x40000000ull ? n_lines - done : 0x40000000ull;  // 32-bit line index
+                uint32_t *sync = static_cast<uint32_t *>(c->team_sync);
+                HIP_TRY(c, hipMemsetAsync(sync, 0, large_team_sync_bytes(), c->stream));
+                a.n_lines = nl;
+                a.iq = d_first + done * (uint64_t)hop * a.bps;
+                a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+                if (c->opt_large_team == 3) {
+                    HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sync + large_team_abort_word()), 1, 1, c->stream));
+                } else {
+                    e = launch_spectro_team(a, log2n, f64, tw1, tw2, c->team_scratch, (uint32_t)c->opt_large_ring, sync, c->n_cu,
+                                            &teams_max, false, c->stream, (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
+                    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team launch: %s", hipGetErrorString(e));
+                }
 #ifdef SPEC_TEAM_PROF
-            if (const char *path = getenv("SPEC_TEAM_PROF_OUT")) {  // development aid: dump the per-workgroup wait cycles
-                std::vector<unsigned long long> pf(16 * 1024);
-                HIP_TRY(c, hipMemcpyAsync(pf.data(), static_cast<uint8_t *>(c->team_sync) + large_team_prof_offset_bytes(), pf.size() * 8,
-                                          hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                if (FILE *f = fopen(path, "wb")) { fwrite(pf.data(), 8, pf.size(), f); fclose(f); }
-            }
+                if (const char *path = getenv("SPEC_TEAM_PROF_OUT")) {  // development aid: dump the per-workgroup wait cycles
+                    std::vector<unsigned long long> pf(16 * 1024);
+                    HIP_TRY(c, hipMemcpyAsync(pf.data(), static_cast<uint8_t *>(c->team_sync) + large_team_prof_offset_bytes(), pf.size() * 8,
+                                              hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (FILE *f = fopen(path, "wb")) { fwrite(pf.data(), 8, pf.size(), f); fclose(f); }
+                }
 #endif
-            if (done < n_lines || c->opt_large_team == 2) {
-                // more than one team launch (> 2^30 lines), or no fall-back wanted: check this one now
-                uint32_t aborted = 0;
-                HIP_TRY(c, hipMemcpyAsync(&aborted, static_cast<uint32_t *>(c->team_sync) + large_team_abort_word(), 4,
-                                          hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                if (aborted) return fail(c, SPEC_EDEVICE, "large-N team kernel: a bounded wait timed out (grid not co-resident)");
+                if (c->opt_large_team == 2) {  // no fall-back wanted: a timed-out wait is this call's error
+                    uint32_t aborted = 0;
+                    HIP_TRY(c, hipMemcpyAsync(&aborted, sync + large_team_abort_word(), 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (aborted) return fail(c, SPEC_EDEVICE, "large-N team kernel: a bounded wait timed out (grid not co-resident)");
+                } else {  // one guarded launch: returns at once unless the abort word is set
+                    e = launch_spectro_large_solo(a, log2n, f64, tw1, tw2, c->scratch, solo_grid, c->stream, sync + large_team_abort_word());
+                    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N fall-back launch: %s", hipGetErrorString(e));
+                }
+                done += nl;
             }
+            return SPEC_OK;
         }
-        if (team) {
-            if (c->opt_large_team == 2) return SPEC_OK;
-            run_if = static_cast<uint32_t *>(c->team_sync) + large_team_abort_word();
-        }
-        // four-step path as two launches per chunk of lines
-        // (behind the team kernel too: every chunk is two launches, and 512 guarded launches that return at once
-        // still cost a millisecond per 32 767 lines; the 1 GiB chunk makes it 64)
+        // four-step path as two launches per chunk of lines ("large_team" = 0, and calls of fewer than 64 lines)
+        const uint32_t *run_if = nullptr;
         uint64_t chunk = ((uint64_t)c->opt_large_chunk_mb << 20) / per_line;
         if (chunk == 0) chunk = 1;
         if (chunk > n_lines) chunk = n_lines;

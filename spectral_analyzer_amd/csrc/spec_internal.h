@@ -57,6 +57,10 @@ size_t large_scratch_bytes_per_line(int log2n, bool f64);
 // run_if != nullptr: the kernels start only when *run_if != 0 (the fall-back behind the team kernel)
 hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2,
                                 void *scratch, hipStream_t s, const uint32_t *run_if = nullptr);
+// the fall-back behind the team kernel as ONE guarded launch over all lines: every workgroup owns whole lines and a
+// line-sized intermediate of its own (`scratch` = grid * N complex values); nothing in it waits for another workgroup
+hipError_t launch_spectro_large_solo(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2, void *scratch,
+                                     uint32_t grid, hipStream_t s, const uint32_t *run_if);
 // the same decomposition as ONE persistent launch with the intermediate kept in each XCD's L2 (spec_k_team.hip):
 // `sync` (large_team_sync_bytes(), zeroed on the stream before the call) carries the tickets and ring counters;
 // word large_team_abort_word() is non-zero afterwards when a bounded wait timed out (output incomplete).

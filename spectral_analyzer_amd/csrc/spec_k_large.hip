@@ -178,6 +178,102 @@ __global__ __launch_bounds__(Plan<L2>::WG, 2) void large_rows_kernel(const Large
     }
 }
 
+// ---- the guarded fall-back behind the persistent team kernel: ONE launch for any number of lines ----------------
+// The team kernel (spec_k_team.hip) needs all its workgroups resident at once; on a shared or partitioned GPU its
+// bounded waits time out, it raises the abort word and leaves.  What runs then must not need residency of its own,
+// and it should be ONE guarded launch, not one pair per chunk of lines (64 empty launches per 32 767-line call cost
+// 2-3 % of the step).  Here every workgroup owns whole lines: it runs the column step of all of a line's tiles into
+// a line-sized intermediate of its own (a.scratch: one per workgroup of the grid), then the row step of all tiles
+// from it -- no other workgroup is ever waited for.  Its own stores reach L2 through the CU's write-through L1
+// (s_waitcnt vmcnt(0) + barrier), the reads bypass that L1 (non-temporal), so a line's intermediate is never read
+// stale although the buffer is rewritten line after line.  No prefetch, no overlap reuse: a correctness path.
+template <typename R, int L1, int L2, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void large_solo_kernel(const LargeArgs a) {
+    using LG = Large<R, L1, L2>;
+    using PA = typename LG::PA;
+    using PB = typename LG::PB;
+    static_assert(PA::WG == 256 && PB::WG == 256, "both steps use 256-thread workgroups");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cx<R> *lds = reinterpret_cast<cx<R> *>(smem);
+    const int tid = threadIdx.x;
+    if (a.run_if && *a.run_if == 0) return;
+    constexpr size_t LINES = (size_t)LG::CA * LG::SA > (size_t)LG::CB * LG::SB ? (size_t)LG::CA * LG::SA : (size_t)LG::CB * LG::SB;
+    cx<R> *tab_a = lds + LINES, *tab_b = tab_a + PA::N;
+    for (int e = tid; e < PA::N; e += 256) tab_a[e] = static_cast<const cx<R> *>(a.tw1)[e];
+    for (int e = tid; e < PB::N; e += 256) tab_b[e] = static_cast<const cx<R> *>(a.tw2)[e];
+    __syncthreads();
+    const R *__restrict__ win = static_cast<const R *>(a.win);
+    const cx<double> *__restrict__ twn = static_cast<const cx<double> *>(a.twn);
+    cx<R> *mid = static_cast<cx<R> *>(a.scratch) + (uint64_t)blockIdx.x * LG::N;  // [n2][k1], this workgroup's own
+    for (uint32_t line = blockIdx.x; line < a.n_lines; line += gridDim.x) {
+        const uint8_t *src = a.iq + (uint64_t)line * a.hop * a.bps;
+        {   // column step: N1-point transforms over n1 for every column n2, times W_N^(n2 k1)
+            const int q0 = tid % LG::CA, t0 = tid / LG::CA, t1 = tid % PA::T, q1 = tid / PA::T;
+            for (uint32_t c0 = 0; c0 < (uint32_t)LG::N2; c0 += LG::CA) {
+                cx<R> v[PA::E];
+#pragma unroll
+                for (int m = 0; m < PA::E; ++m) {
+                    const uint32_t n = (uint32_t)(t0 + m * PA::T) * LG::N2 + c0 + q0;
+                    if constexpr (DIRECT) v[m] = *reinterpret_cast<const cx<R> *>(src + (uint64_t)n * sizeof(cx<R>));
+                    else v[m] = decode_sample<R>(src + (uint64_t)n * a.bps, a.kind, a.be != 0);
+                    if (win) { const R w = win[n]; v[m].x *= w; v[m].y *= w; }
+                }
+                fft_line_remap<R, L1>(v, t0, lds + (size_t)q0 * LG::SA, t1, lds + (size_t)q1 * LG::SA, tab_a);
+                const uint32_t n2 = c0 + q1;
+                cx<double> w = twn[n2 * (uint32_t)t1];
+                const cx<double> step = twn[n2 * (uint32_t)PA::T];
+                cx<R> *dst = mid + (uint64_t)n2 * LG::N1;
+#pragma unroll
+                for (int m = 0; m < PA::E; ++m) {
+                    const cx<double> z = cmul(cx<double>{(double)v[m].x, (double)v[m].y}, w);
+                    dst[t1 + m * PA::T] = cx<R>{(R)z.x, (R)z.y};
+                    w = cmul(w, step);
+                }
+                __syncthreads();  // the line buffers are rewritten by the next tile
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's intermediate is in L2
+        __syncthreads();
+        {   // row step: N2-point transforms over n2 for every row k1, epilogue (SS:76-82)
+            const int q0 = tid % LG::CB, t0 = tid / LG::CB;
+            const uint64_t base = (uint64_t)line * LG::N;
+            for (uint32_t r0 = 0; r0 < (uint32_t)LG::N1; r0 += LG::CB) {
+                cx<R> v[PB::E];
+                typedef R r2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int m = 0; m < PB::E; ++m) {  // L1 bypassed: the buffer was rewritten since this CU last read it
+                    const r2 u = __builtin_nontemporal_load(reinterpret_cast<const r2 *>(mid + (uint64_t)(t0 + m * PB::T) * LG::N1 + r0 + q0));
+                    v[m] = cx<R>{u.x, u.y};
+                }
+                fft_line<R, L2>(v, t0, lds + (size_t)q0 * LG::SB, tab_b);
+#pragma unroll
+                for (int m = 0; m < PB::E; ++m) {
+                    const uint32_t k = (r0 + q0) + (uint32_t)LG::N1 * (t0 + m * PB::T);
+                    store_bin<R>(a.out, base + ((k + LG::N / 2) & (LG::N - 1)), v[m], a.out_fmt);  // SS:78
+                }
+                __syncthreads();
+            }
+        }
+        // the row step's reads of `mid` are complete (consumed by its transforms) before the next line's stores
+    }
+}
+
+template <typename R, int L1, int L2> size_t solo_lds_bytes() {
+    using LG = Large<R, L1, L2>;
+    const size_t lines = (size_t)LG::CA * LG::SA > (size_t)LG::CB * LG::SB ? (size_t)LG::CA * LG::SA : (size_t)LG::CB * LG::SB;
+    return (lines + LG::PA::N + LG::PB::N) * sizeof(cx<R>);
+}
+
+template <typename R, int L1, int L2> hipError_t launch_solo(const LargeArgs &a, uint32_t grid, hipStream_t s) {
+    const bool direct = !a.be && a.kind == (sizeof(R) == 8 ? K_CF64 : K_CF32);
+    auto fn = direct ? &large_solo_kernel<R, L1, L2, true> : &large_solo_kernel<R, L1, L2, false>;
+    const size_t lds = solo_lds_bytes<R, L1, L2>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
 template <typename R, int L1, int L2> hipError_t launch_large(const LargeArgs &a, hipStream_t s) {
     using LG = Large<R, L1, L2>;
     // samples that already are cx<R> in memory need no decode
@@ -209,6 +305,28 @@ bool large_split(int log2n, bool f64, int *l1, int *l2) {
 }
 
 size_t large_scratch_bytes_per_line(int log2n, bool f64) { return ((size_t)1 << log2n) * (f64 ? 16 : 8); }
+
+// One guarded launch over all n_lines (n_lines < 2^32): `scratch` holds grid line-sized intermediates.
+hipError_t launch_spectro_large_solo(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2, void *scratch,
+                                     uint32_t grid, hipStream_t s, const uint32_t *run_if) {
+    LargeArgs a{};
+    a.run_if = run_if;
+    a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.bps = w.bps; a.kind = w.kind; a.be = w.be;
+    a.tw1 = tw1; a.tw2 = tw2; a.twn = w.tw; a.win = w.win; a.scratch = scratch; a.out = w.out; a.out_fmt = w.out_fmt;
+    if (f64) {
+        switch (log2n) {
+        case 14: return launch_solo<double, 7, 7>(a, grid, s);
+        case 15: return launch_solo<double, 7, 8>(a, grid, s);
+        case 16: return launch_solo<double, 8, 8>(a, grid, s);
+        }
+    } else {
+        switch (log2n) {
+        case 15: return launch_solo<float, 7, 8>(a, grid, s);
+        case 16: return launch_solo<float, 8, 8>(a, grid, s);
+        }
+    }
+    return hipErrorInvalidValue;
+}
 
 hipError_t launch_spectro_large(const WfArgs &w, int log2n, bool f64, const void *tw1, const void *tw2,
                                 void *scratch, hipStream_t s, const uint32_t *run_if) {

@@ -89,6 +89,66 @@ def test_team_and_two_launch_paths_agree(svc, oracle):
         svc.set_option("large_team", 1)
 
 
+@pytest.mark.parametrize("datatype,nfft,hop,n_lines,window,fmt", [
+    ("cf64_le", 65536, 32768, 300, sa.WIN_RECT, sa.OUT_DB20_F64), ("cf64_be", 16384, 5000, 70, sa.WIN_HANN, sa.OUT_POW_F64),
+    ("cf32_le", 65536, 32768, 257, sa.WIN_RECT, sa.OUT_DB20_F32), ("ci16_le", 32768, 32768, 64, sa.WIN_HANN, sa.OUT_POW_F32)])
+def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nfft, hop, n_lines, window, fmt):
+    """Behind the persistent team kernel sits ONE guarded launch (large_solo_kernel: every workgroup owns whole lines
+    and an intermediate of its own, nothing waits for another workgroup) instead of round 2's launch pair per 1 GiB
+    chunk.  "large_team" = 3 runs it as if the team kernel had timed out: its lines are the two-launch path's lines
+    BIT FOR BIT (the same sub-transforms and inter-step twiddles), more lines than workgroups included; and with the
+    default dispatch it leaves the team kernel's result alone (its guard reads the abort word, which stays 0)."""
+    import torch
+    iq = torch.from_numpy(oracle.synth_iq(datatype, 31, 3, (n_lines - 1) * hop + nfft)).cuda()
+    try:
+        out = {}
+        for mode in (0, 3, 2, 1):
+            svc.set_option("large_team", mode)
+            out[mode] = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines + 1, hop=hop, window=window, out_fmt=fmt).clone()
+            torch.cuda.synchronize()
+        assert torch.equal(out[3], out[0])
+        assert torch.equal(out[1], out[2])
+        assert bool((out[3][n_lines] == -150.0).all())
+    finally:
+        svc.set_option("large_team", 1)
+
+
+# ---- team kernel vs two-launch path, EVERY value of a full-size output (the hand-off between workgroups rests on the
+# hardware's L2 behaviour: a stale tile would be a rare wrong 16-column stripe, which sampled checks miss) -------------
+@pytest.mark.parametrize("datatype,fmt,tol", [("cf64_le", sa.OUT_POW_F64, 1e-12), ("cf32_le", sa.OUT_POW_F32, 4e-6)])
+def test_team_and_two_launch_agree_on_every_value_at_full_size(svc, datatype, fmt, tol):
+    """BASELINE configs[4] at its per-GPU shape (65536-point cf64 -> f64, hop 32768, 2^30 samples, 32 767 lines) and
+    the same shape in cf32: the whole output of the team kernel ("large_team" = 2: no fall-back, a timed-out wait is an
+    error) against the whole output of the two-launch path, all 32 767 x 65 536 values compared on the device.
+    |dP| <= tol * (the line's peak power): fp64 1e-12; fp32 4e-6 (the two paths use different radix plans -- 8 x 8 x 4
+    against 16 x 16 -- so they differ by fp32 rounding, a stale stripe would differ by the stripe)."""
+    import torch
+    nfft, hop, S = 65536, 32768, 1 << 30
+    n_lines = (S - nfft) // hop + 1
+    iq = svc.synth_iq(datatype, 0x5EC7A11A, 0, S)
+    try:
+        svc.set_option("large_team", 2)
+        team = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=fmt)
+        torch.cuda.synchronize()
+        svc.set_option("large_team", 0)
+        two = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=fmt)
+        torch.cuda.synchronize()
+        worst, bad_lines = 0.0, 0
+        for a in range(0, n_lines, 1024):                        # 1024 lines (up to 512 MiB) at a time
+            t, w = team[a:a + 1024], two[a:a + 1024]
+            peak = w.amax(dim=1, keepdim=True)
+            rel = ((t - w).abs() / peak).amax(dim=1)
+            worst = max(worst, float(rel.max()))
+            bad_lines += int((rel > tol).sum())
+            del t, w, peak, rel
+        assert bad_lines == 0 and worst <= tol, (bad_lines, worst)
+        assert bool(torch.isfinite(team).all())
+    finally:
+        svc.set_option("large_team", 1)
+        del iq
+        torch.cuda.empty_cache()
+
+
 def test_team_kernel_repeated_launches_are_identical(team, oracle):
     # placement of workgroups may differ from launch to launch; the lines must not
     import torch
