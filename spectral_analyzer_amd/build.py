@@ -51,12 +51,24 @@ def _stamp(extra) -> str:
     return " ".join([*FLAGS, *extra])
 
 
-def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+# named variants: what they are compiled with, and which translation units the flags touch (the others are taken from
+# the product build as they are)
+VARIANTS = {
+    # the team kernel's two experiment geometries (large_wg = 256 / 1024): measured slower, kept
+    # under test (tests/test_gpu_large.py), not carried by the product library
+    "teamvar": (["-DSPEC_TEAM_VARIANTS"], ["spec_k_team.hip"]),
+}
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=(), only=None) -> str:
     """Build the product library, or -- ``variant`` -- an EXPERIMENT library beside it
     (lib/libspecgpu_<variant>.so, objects under build/<variant>/, compiled with ``extra_flags``, e.g. the
     SPEC_ABL_* ablation macros whose results are wrong by construction).  An experiment never overwrites the
     product: the product build takes no extra flags, and its freshness test also compares the flag stamp
-    stored beside the library, so a library built any other way is rebuilt."""
+    stored beside the library, so a library built any other way is rebuilt.  ``only``: the translation units the
+    flags affect -- the rest is linked from the product's objects (built first when stale)."""
+    if variant in VARIANTS and not extra_flags:
+        extra_flags, only = VARIANTS[variant]
     extra = list(extra_flags)
     if variant:
         lib = os.path.join(LIBDIR, "libspecgpu_%s.so" % variant)
@@ -72,8 +84,18 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
         return lib
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(objdir, exist_ok=True)
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(lambda src: _compile(src, objdir, extra), SOURCES))
+    if variant and only:
+        build(force=False, verbose=verbose)  # the product's objects, fresh
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(only))) as ex:
+            mine = dict(zip(only, ex.map(lambda src: _compile(src, objdir, extra), only)))
+        objs = [mine.get(src) or os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o") for src in SOURCES]
+        missing = [o for o in objs if not os.path.exists(o)]
+        if missing:  # the product library was built elsewhere (objects do not travel): compile everything
+            with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+                objs = list(ex.map(lambda src: _compile(src, objdir, extra if src in only else []), SOURCES))
+    else:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+            objs = list(ex.map(lambda src: _compile(src, objdir, extra), SOURCES))
     cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -108,7 +130,7 @@ def build_jni(verbose: bool = False):
 
 if __name__ == "__main__":
     # python -m spectral_analyzer_amd.build [--force] [--variant NAME -- -DSPEC_ABL_X ...]
-    if "--variant" in sys.argv:
+    if "--variant" in sys.argv:  # a named variant (VARIANTS) needs no flags
         i = sys.argv.index("--variant")
         flags = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
         build(force=True, verbose=True, variant=sys.argv[i + 1], extra_flags=flags)

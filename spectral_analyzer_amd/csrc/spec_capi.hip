@@ -503,6 +503,9 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             const uint32_t ring = (uint32_t)c->opt_large_ring;
             hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, nullptr, ring, nullptr, c->n_cu, &teams_max, true, c->stream,
                                                (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
+            if (e == hipErrorNotSupported)
+                return fail(c, SPEC_EUNSUPPORTED, "large_wg = %lld is an experiment geometry: build the variant library "
+                            "(python -m spectral_analyzer_amd.build --variant teamvar)", (long long)c->opt_large_wg);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team query: %s", hipGetErrorString(e));
             if ((st = grow(c, &c->team_scratch, &c->team_scratch_bytes, (size_t)(teams_max ? teams_max : 1) * ring * per_line)) != SPEC_OK) return st;
             if ((st = grow(c, &c->team_sync, &c->team_sync_bytes, large_team_sync_bytes())) != SPEC_OK) return st;

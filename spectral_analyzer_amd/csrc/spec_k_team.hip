@@ -562,20 +562,29 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 // leaves them in flight.  Per line: [poll slot of line i + 1] [stores of line i] [loads of line i + 2].
                 constexpr int NLD = (HALF ? NEWH : TE) / EPL;  // LOWER bound of the loads issued behind a line's stores
                 const DmaCoords dc = dma_coords(PA::C);
-                auto issue = [&](uint32_t line, auto first_tag) {
-                    constexpr int FIRST = decltype(first_tag)::value;
-                    static_assert(FIRST % EPL == 0, "whole instructions");
+                auto issue_rows = [&](uint32_t line, auto first_tag, auto end_tag) {  // rows [FIRST, END) of the line's tile
+                    constexpr int FIRST = decltype(first_tag)::value, END = decltype(end_tag)::value;
+                    static_assert(FIRST % EPL == 0 && END % EPL == 0, "whole instructions");
                     const uint8_t *src = a.iq + (uint64_t)line * a.hop * sizeof(cx<R>);
 #pragma unroll
-                    for (int j = FIRST / EPL; j < NI; ++j)
+                    for (int j = FIRST / EPL; j < END / EPL; ++j)
                         glds16<0>(src + (uint64_t)((dc.t + (EPL * j + dc.mm) * PA::T) * N2 + c0 + dc.q) * sizeof(cx<R>), land_addr + 1024u * j);
                 };
+                auto issue = [&](uint32_t line, auto first_tag) { issue_rows(line, first_tag, std::integral_constant<int, TE>{}); };
                 // at the start of a block of lines all eight rows are requested (the counted wait then also waits for
-                // the first four of them, once per block)
+                // the first four of them, once per block).  The NLD loads the counted wait relies on -- the upper half
+                // at 50 % overlap, all rows otherwise -- are issued UNCONDITIONALLY, the lower half in front of them
+                // where it is needed: every control-flow path from a line's stores to the wait carries at least NLD
+                // younger loads (tools/check_team_handoff.py R1 walks the paths of the ISA)
                 auto issue_next = [&](uint32_t i_next) {
                     const uint32_t ic = i_next < my_lines ? i_next : my_lines - 1;  // tail: a valid line again, unused
-                    if (HALF && follows(ic)) issue(line_of(ic), std::integral_constant<int, NEWH>{});
-                    else issue(line_of(ic), std::integral_constant<int, 0>{});
+                    const uint32_t ln = line_of(ic);
+                    if constexpr (HALF) {
+                        if (!follows(ic)) issue_rows(ln, std::integral_constant<int, 0>{}, std::integral_constant<int, NEWH>{});
+                        issue_rows(ln, std::integral_constant<int, NEWH>{}, std::integral_constant<int, TE>{});
+                    } else {
+                        issue(ln, std::integral_constant<int, 0>{});
+                    }
                 };
                 cx<R> cur[TE];
                 issue(line_of(0), std::integral_constant<int, 0>{});
@@ -741,6 +750,12 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         PassTw<R, L2, WG> twr;
         constexpr bool TWREG = !DENSE;
         if constexpr (TWREG) twr.load(t0, tab);
+        // The whole walk over this workgroup's lines is specialised on the output format: the format is chosen ONCE,
+        // below, and the line loop's stores are a straight-line sequence -- the counted waits of the pipelined form
+        // count exactly those stores, and tools/check_team_handoff.py can follow every path of the loop in the ISA
+        // (with the format switch inside the loop "no format at all" was a path of the control-flow graph).
+        auto row_side = [&](auto out_fmt_tag) {
+        constexpr int OUTFMT = decltype(out_fmt_tag)::value;
         // the epilogue of one line (SS:76-82) and its stores; between(4) sits in front of the first store
         auto epilogue = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
             const uint64_t base = (uint64_t)line * N;
@@ -807,12 +822,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #endif
             };
             asm volatile("" ::: "memory");
-            switch (a.out_fmt) {
-            case OUT_DB20_F32: emit(std::integral_constant<int, OUT_DB20_F32>{}); break;
-            case OUT_POW_F32: emit(std::integral_constant<int, OUT_POW_F32>{}); break;
-            case OUT_DB20_F64: emit(std::integral_constant<int, OUT_DB20_F64>{}); break;
-            default: emit(std::integral_constant<int, OUT_POW_F64>{}); break;
-            }
+            emit(std::integral_constant<int, OUTFMT>{});
             asm volatile("" ::: "memory");
         };
         // The rest of one line behind its first pass and exchange.
@@ -1032,6 +1042,18 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 }
             }
         }
+        };  // row_side
+        if constexpr (sizeof(R) == 4) {  // an fp32 pipeline only ever stores floats (spec_capi.hip run_lines)
+            if (a.out_fmt == OUT_DB20_F32) row_side(std::integral_constant<int, OUT_DB20_F32>{});
+            else row_side(std::integral_constant<int, OUT_POW_F32>{});
+        } else {
+            switch (a.out_fmt) {
+            case OUT_DB20_F32: row_side(std::integral_constant<int, OUT_DB20_F32>{}); break;
+            case OUT_POW_F32: row_side(std::integral_constant<int, OUT_POW_F32>{}); break;
+            case OUT_DB20_F64: row_side(std::integral_constant<int, OUT_DB20_F64>{}); break;
+            default: row_side(std::integral_constant<int, OUT_POW_F64>{}); break;
+            }
+        }
     }
 }
 
@@ -1062,10 +1084,17 @@ hipError_t launch_team_wg(const TeamArgs &a, int n_cu, uint32_t *teams_max, hipS
 }
 template <typename R, int L1, int L2>
 hipError_t launch_team(const TeamArgs &a, int wg, int n_cu, uint32_t *teams_max, hipStream_t s, bool query_only) {
-    // 512: one workgroup per CU, 16-wide tiles.  256: two per CU, 8-wide tiles, one of either role on every CU.
-    // 1024 selects the dense form: two 512-thread workgroups per CU
+    // 512: one workgroup per CU, 16-wide tiles -- the only geometry the default dispatch reaches, and the only one the
+    // product library carries.  The two experiment geometries (measured slower) are compiled only with
+    // -DSPEC_TEAM_VARIANTS (python -m spectral_analyzer_amd.build --variant teamvar; tests/test_gpu_large.py runs them
+    // from that library): 256 = two workgroups per CU, 8-wide tiles, one of either role on every CU; 1024 = the dense
+    // form, two 512-thread workgroups per CU at 128 registers.
+#ifdef SPEC_TEAM_VARIANTS
     if (wg == 1024) return launch_team_wg<R, L1, L2, 512, true>(a, n_cu, teams_max, s, query_only);
     if (wg == 256) return launch_team_wg<R, L1, L2, 256, false>(a, n_cu, teams_max, s, query_only);
+#else
+    if (wg != 512) return hipErrorNotSupported;
+#endif
     return launch_team_wg<R, L1, L2, 512, false>(a, n_cu, teams_max, s, query_only);
 }
 

@@ -1,6 +1,10 @@
 """Lines longer than the LDS holds (fp32 nfft >= 32768, fp64 nfft >= 16384; BASELINE configs[4] is the
 65536-point cf64 case): the persistent "team" kernel that keeps the four-step intermediate in each XCD's
 L2 (spec_k_team.hip) against the oracle, against the two-launch path, and through the default dispatch."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -9,18 +13,54 @@ from test_gpu_parity import check_fp32, check_fp64
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = os.environ.get("SPEC_LIB_VARIANT") == "teamvar"
+
 
 @pytest.fixture(params=[512, 256], ids=["wg512", "wg256"])
 def team(svc, request):
     """large_team = 2: the team kernel for any number of lines, no fall-back -- a timed-out wait is an error.
-    Both geometries: one 512-thread workgroup per CU (16-wide tiles), two 256-thread workgroups per CU (8-wide
-    tiles, one of either role on every CU)."""
+    Both geometries: one 512-thread workgroup per CU (16-wide tiles: the product's), two 256-thread workgroups per CU
+    (8-wide tiles, one of either role on every CU: an experiment geometry that only the variant library
+    lib/libspecgpu_teamvar.so carries -- test_experiment_geometries_in_the_variant_library runs these cases from it)."""
+    if request.param != 512 and not VARIANT:
+        pytest.skip("experiment geometry: run from the variant library (test_experiment_geometries_in_the_variant_library)")
     svc.set_option("large_team", 2)
     svc.set_option("large_wg", request.param)
     yield svc
     svc.set_option("large_team", 1)
     svc.set_option("large_ring", 2)
     svc.set_option("large_wg", 0)
+
+
+def test_experiment_geometries_in_the_variant_library():
+    """The product library carries only the team kernel the default dispatch reaches (512-thread workgroups).  The two
+    geometries that were measured slower (large_wg = 256 / 1024) are compiled into lib/libspecgpu_teamvar.so
+    (-DSPEC_TEAM_VARIANTS, built by __graft_entry__.build()); this test runs the wg256 cases of this file against that
+    library in ONE child process, and checks that the product library refuses the knob instead of silently taking the
+    default."""
+    lib = os.path.join(ROOT, "spectral_analyzer_amd", "lib", "libspecgpu_teamvar.so")
+    if VARIANT:
+        pytest.skip("already inside the variant run")
+    assert os.path.exists(lib), "variant library missing: python -m spectral_analyzer_amd.build --variant teamvar"
+    env = dict(os.environ, SPEC_LIB_VARIANT="teamvar")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "wg256",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1].split("passed")[0]
+
+
+def test_product_library_refuses_the_experiment_geometries(svc, oracle):
+    import torch
+    if VARIANT:
+        pytest.skip("variant library")
+    iq = torch.from_numpy(oracle.synth_iq("cf32_le", 1, 0, 65 * 16384 + 32768)).cuda()
+    try:
+        svc.set_option("large_wg", 256)
+        with pytest.raises(NotImplementedError, match="experiment geometry"):
+            svc.compute_waterfall(iq, 0, 32768, "cf32_le", 65, hop=16384)
+    finally:
+        svc.set_option("large_wg", 512)
 
 
 CASES = [  # datatype, nfft, hop, n_lines, window, fp64 output

@@ -85,8 +85,9 @@ def main():
     else:
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "team.s")
+            # -DSPEC_TEAM_VARIANTS: the experiment geometries of lib/libspecgpu_teamvar.so are scanned with the product's
             subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast",
-                                   "--cuda-device-only", "-S", SRC, "-o", out])
+                                   "-DSPEC_TEAM_VARIANTS", "--cuda-device-only", "-S", SRC, "-o", out])
             text = open(out).read()
     kernels, loads, dma, bad = scan(text)
     print("kernels %d, LDS-DMA loads %d, inline-assembly loads with a register destination %d, "
