@@ -127,11 +127,14 @@ void *spec_stream(const spec_ctx *ctx);
  *                     launch for any number of lines and no fall-back (the call then waits for the kernel and returns
  *                     SPEC_EDEVICE if one of its bounded waits timed out); 3 (tests) = the fall-back alone, as if the
  *                     persistent launch had timed out
- *   "large_ring" = 1..4  line-sized slots of intermediate per team of the persistent launch (default 2: the slots share the
- *                     XCD's 4 MiB L2 with the input and output streams; 3 measured 5 % slower, 4 20 %)
- *   "large_wg" = 256 | 512  threads per workgroup of the persistent launch (default 512: one workgroup per CU, 16-bin =
- *                     128-byte output runs; 256: two per CU, one column and one row workgroup on every CU -- measured
- *                     slower, kept for tests)
+ *   "large_ring" = 0..4  line-sized slots of intermediate per team of the persistent launch.  0 (default) = automatic:
+ *                     2 for fp64 lines (the slots share the XCD's 4 MiB L2 with the input and output streams; 3 measured
+ *                     5 % slower, 4 20 %), 3 for fp32 lines (slots of half the size: 3-4 % faster than 2)
+ *   "large_wg" = 512 | 256 | 1024  geometry of the persistent launch.  512 (default): one 512-thread workgroup per CU,
+ *                     16-bin = 128-byte output runs -- the only one the product library carries.  256 (two workgroups per
+ *                     CU, one of either role on every CU) and 1024 (two 512-thread workgroups per CU at 128 registers) were
+ *                     measured slower and live in the variant library lib/libspecgpu_teamvar.so
+ *                     (python -m spectral_analyzer_amd.build --variant teamvar); the product returns SPEC_EUNSUPPORTED
  *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
  *   "render_fused" = 0 | 1   spec_waterfall_render stores only the bins the image samples (default 1; 0 = full
  *                     dB tile, then the colour kernel: the two forms give identical pixels)

@@ -57,6 +57,8 @@ VARIANTS = {
     # the team kernel's two experiment geometries (large_wg = 256 / 1024): measured slower, kept
     # under test (tests/test_gpu_large.py), not carried by the product library
     "teamvar": (["-DSPEC_TEAM_VARIANTS"], ["spec_k_team.hip"]),
+    # development aid: lane-0 cycle counters inside the team kernel (tools/team_prof.py)
+    "tPROF": (["-DSPEC_TEAM_PROF"], ["spec_k_team.hip", "spec_capi.hip"]),
 }
 
 

@@ -63,7 +63,7 @@ struct spec_ctx {
     void *team_sync = nullptr;    size_t team_sync_bytes = 0;     //                   tickets, ring counters, abort word    // spec_welch_psd_planar_f64: interleaved copy of the burst
     // tuning / testing knobs (spec_set_option)
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
-    int64_t opt_large_team = 1, opt_large_ring = 2, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
+    int64_t opt_large_team = 1, opt_large_ring = 0, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
     int64_t opt_welch_two_pass = 0;
     int n_cu = 256;
     // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
@@ -316,7 +316,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "rec_pread")) c->opt_rec_pread = value != 0;
     else if (!strcmp(key, "welch_two_pass")) c->opt_welch_two_pass = value != 0;
     else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 3 ? 3 : value);
-    else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 1 ? 1 : (value > 4 ? 4 : value);
+    else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 0 ? 0 : (value > 4 ? 4 : value);
     else if (!strcmp(key, "large_wg")) c->opt_large_wg = value == 256 ? 256 : (value == 1024 ? 1024 : 512);
     else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
@@ -500,7 +500,10 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         const bool team = c->opt_large_team >= 2 || (c->opt_large_team == 1 && n_lines >= 64);
         if (team) {
             uint32_t teams_max = 0;
-            const uint32_t ring = (uint32_t)c->opt_large_ring;
+            // line-sized slots of intermediate per team: they share the XCD's 4 MiB L2 with the input and output streams.
+            // fp64 lines (1 MiB slots at 65536 points): two -- a third is written back before it is reused (measured 5 %
+            // slower); fp32 lines (half the size): three fit, and the extra slack between the two sides is worth 3-4 %
+            const uint32_t ring = c->opt_large_ring > 0 ? (uint32_t)c->opt_large_ring : (f64 ? 2u : 3u);
             hipError_t e = launch_spectro_team(a, log2n, f64, tw1, tw2, nullptr, ring, nullptr, c->n_cu, &teams_max, true, c->stream,
                                                (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
             if (e == hipErrorNotSupported)
@@ -523,13 +526,13 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                 if (c->opt_large_team == 3) {
                     HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sync + large_team_abort_word()), 1, 1, c->stream));
                 } else {
-                    e = launch_spectro_team(a, log2n, f64, tw1, tw2, c->team_scratch, (uint32_t)c->opt_large_ring, sync, c->n_cu,
+                    e = launch_spectro_team(a, log2n, f64, tw1, tw2, c->team_scratch, ring, sync, c->n_cu,
                                             &teams_max, false, c->stream, (int)c->opt_large_wg, (uint32_t)c->opt_large_block);
                     if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team launch: %s", hipGetErrorString(e));
                 }
 #ifdef SPEC_TEAM_PROF
                 if (const char *path = getenv("SPEC_TEAM_PROF_OUT")) {  // development aid: dump the per-workgroup wait cycles
-                    std::vector<unsigned long long> pf(16 * 1024);
+                    std::vector<unsigned long long> pf(16 * 1024 + 64 * 32 * 8);  // per-workgroup words + the event trace
                     HIP_TRY(c, hipMemcpyAsync(pf.data(), static_cast<uint8_t *>(c->team_sync) + large_team_prof_offset_bytes(), pf.size() * 8,
                                               hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(c, hipStreamSynchronize(c->stream));

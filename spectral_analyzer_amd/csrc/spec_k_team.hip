@@ -236,7 +236,17 @@ template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_wai
             for (int k = 0; k < 8; ++k) o[8 + k] = ph[k];                                                       \
         }                                                                                                       \
     } while (0)
+// event trace of ONE team (team 0), lines TRACE_L0 .. TRACE_L0 + 31, lane 0 of every member workgroup: wall-clock ticks
+// (100 MHz, the same clock on every CU) behind the per-workgroup words -- tools/team_trace.py prints the hand-offs
+#define TRACE_L0 1000u
+#define TRACE(ev, i)                                                                                                  \
+    do {                                                                                                              \
+        if (threadIdx.x == 0 && team == 0 && (i) >= TRACE_L0 && (i) < TRACE_L0 + 32u)                                   \
+            (reinterpret_cast<unsigned long long *>(a.sync + TEAM_SYNC_WORDS) + 16384ull)[((size_t)member * 32u + ((i) - TRACE_L0)) * 8u + (ev)] = \
+                (unsigned long long)wall_clock64();                                                                   \
+    } while (0)
 #else
+#define TRACE(ev, i) (void)0
 #define PROF_DECL (void)0
 #define PROF_T0() (void)0
 #define PROF_ADD(k) (void)0
@@ -600,6 +610,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #endif
                 for (uint32_t i = 0; i < my_lines; ++i) {
                     const uint32_t slot = i % a.ring, round = i / a.ring;
+                    TRACE(0, i);
                     cx<R> v[TE];
 #pragma unroll
                     for (int m = 0; m < TE; ++m) v[m] = cur[m];
@@ -614,9 +625,11 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     if (lane == 0 && pending != NONE && atomicAdd(&s_arrive, 1u) + 1 == WAVES * i)
                         __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     PROF_ADD(1);
+                    TRACE(1, i);
                     PROF_T0();
                     __syncthreads();
                     PROF_ADD(4);
+                    TRACE(2, i);
                     // was the slot free when the poll was taken?  (first lines: nobody has used it yet.)  The poll of
                     // line i landed in word i & 1 before wave 0 came to the barrier above; that word is rewritten two
                     // lines on
@@ -633,6 +646,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     wave_sync();
                     xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
                     finish(v);
+                    TRACE(3, i);
                     // cur <- line i + 1: its rows were requested a whole line ago (behind the last line: unused)
                     PROF_T0();
                     vm_wait<0>();
@@ -650,6 +664,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     if (!slot_free && !team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
                     PROF_ADD(3);
 #endif
+                    TRACE(4, i);
                     if (tid == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, pland_addr + 128u * ((i + 1) & 1u));  // before the stores
                     cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
                     asm volatile("" ::: "memory");
@@ -658,6 +673,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     asm volatile("" ::: "memory");  // the loads below stay behind the stores above
                     pending = slot;
                     issue_next(i + 2);
+                    TRACE(5, i);
                     __syncthreads();  // this line's last LDS reads | the next line's first LDS writes
                 }
                 vm_wait<0>();
@@ -938,9 +954,11 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #ifdef SPEC_TEAM_PROF
                 ph_t = __builtin_readcyclecounter();
 #endif
+                TRACE(0, i);
                 PROF_T0();
                 vm_wait<TEAM_NST>();  // tile i and the poll have landed; the stores of line i - 1 fly on
                 PROF_ADD(1);
+                TRACE(1, i);
                 cx<R> v[TE];
 #pragma unroll
                 for (int m = 0; m < TE; ++m) v[m] = land[64 * m + lane];
@@ -963,6 +981,8 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #else
                 const bool ahead = s_next != 0;
 #endif
+                TRACE(2, i);
+                if (ahead) { TRACE(7, i); }
                 auto requests = [&](auto stage) {  // every request is older than the line's output stores
                     constexpr int ST = decltype(stage)::value, Q = TE / 4;
                     if constexpr (ST == 4) {
@@ -988,6 +1008,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #else
                 rest_of_line_sx(v, line_of(i), requests);
 #endif
+                TRACE(4, i);
                 if (!ahead && i + 1 < my_lines) {  // the column side is not ahead: wait for it here
                     PROF_T0();
                     PROF_INC(5);
@@ -995,10 +1016,12 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
 #endif
                     PROF_ADD(3);
+                    TRACE(5, i);
                     PROF_T0();
                     issue(i + 1);
                     vm_wait<0>();  // nothing younger to leave in flight on this path
                     PROF_ADD(2);
+                    TRACE(6, i);
                 }
             }
 #ifdef SPEC_TEAM_PROF
@@ -1101,7 +1124,7 @@ hipError_t launch_team(const TeamArgs &a, int wg, int n_cu, uint32_t *teams_max,
 }  // namespace
 
 #ifdef SPEC_TEAM_PROF
-size_t large_team_sync_bytes() { return (size_t)TEAM_SYNC_WORDS * sizeof(uint32_t) + 1024 * 128; }  // + 16 words x 1024 workgroups
+size_t large_team_sync_bytes() { return (size_t)TEAM_SYNC_WORDS * sizeof(uint32_t) + 1024 * 128 + 64 * 32 * 8 * 8; }  // + 16 words x 1024 workgroups + the event trace
 #else
 size_t large_team_sync_bytes() { return (size_t)TEAM_SYNC_WORDS * sizeof(uint32_t); }
 #endif

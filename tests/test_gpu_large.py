@@ -29,7 +29,7 @@ def team(svc, request):
     svc.set_option("large_wg", request.param)
     yield svc
     svc.set_option("large_team", 1)
-    svc.set_option("large_ring", 2)
+    svc.set_option("large_ring", 0)
     svc.set_option("large_wg", 0)
 
 
