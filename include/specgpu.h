@@ -237,7 +237,8 @@ spec_status spec_waterfall_multi(spec_ctx *const *ctx, uint32_t n_ctx, const voi
  * with 64-bit offsets and no size limit.  The library maps the whole file itself (64-bit length) and
  * feeds the same two-deep device pipeline as spec_waterfall from the mapping; where the mapping is
  * refused, or with spec_set_option("rec_pread", 1), it reads the slices it needs with pread into a
- * pinned two-slot ring instead. */
+ * pinned two-slot ring instead.  A file that shrinks after it was opened is noticed (fstat before every call) and read
+ * with pread for that call -- bytes past the new end read as zero -- instead of touching the mapping past its end. */
 typedef struct spec_recording spec_recording;
 spec_status spec_open_recording(spec_ctx *ctx, const char *data_path, uint64_t header_bytes,
                                 spec_recording **out);

@@ -32,6 +32,8 @@ public class SpectralService implements AutoCloseable {
         System.loadLibrary("specgpu_jni");
     }
 
+    private static final java.lang.ref.Cleaner CLEANER = java.lang.ref.Cleaner.create();
+
     private final long handle;
 
     /** Binds GPU 0 (override with -Dspecgpu.device=N). */
@@ -170,9 +172,18 @@ public class SpectralService implements AutoCloseable {
      */
     public final class Recording implements AutoCloseable {
         private long rec;
+        /** closes the native handle (descriptor + whole-file mapping) should the owner forget to */
+        private final java.lang.ref.Cleaner.Cleanable cleanable;
 
         private Recording(long rec) {
             this.rec = rec;
+            final long[] box = {rec};
+            this.cleanable = CLEANER.register(this, () -> {
+                if (box[0] != 0) {
+                    nativeCloseRecording(box[0]);
+                    box[0] = 0;
+                }
+            });
         }
 
         /** Payload bytes after the header (the mapped buffer's capacity, without the cap). */
@@ -196,10 +207,8 @@ public class SpectralService implements AutoCloseable {
 
         @Override
         public void close() {
-            if (rec != 0) {
-                nativeCloseRecording(rec);
-                rec = 0;
-            }
+            rec = 0;
+            cleanable.clean();  // runs the action once: closes the handle now
         }
     }
 

@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <condition_variable>
@@ -32,6 +33,7 @@ struct spec_ctx {
     // by host threads (the reference runs ExtractDownConvertService on a pool, AsyncExtractDownConvertService
     // .java:27-35,52-55), their calls are serialised.  Recursive: entry points call each other.
     std::recursive_mutex mu;
+    uint64_t gen = 0;  // unique per spec_create: the per-thread error cache is keyed on it, not on the address alone
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -65,6 +67,9 @@ struct spec_ctx {
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
     int64_t opt_large_team = 1, opt_large_ring = 0, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
     int64_t opt_welch_two_pass = 0;
+    // the persistent large-N kernel: a launch whose abort word has not been looked at yet, and the verdict once a
+    // bounded wait did time out on this context (shared / partitioned GPU): it is not tried again
+    bool team_check_pending = false, team_disabled = false;
     int n_cu = 256;
     // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
     // them against the compute stream, created on first use
@@ -98,6 +103,8 @@ static thread_local std::string g_create_err;
 // the calling thread's own last failure (a context shared by threads has one `err` for all of them)
 static thread_local std::string t_err;
 static thread_local const spec_ctx *t_err_ctx = nullptr;
+static thread_local uint64_t t_err_gen = 0;
+static std::atomic<uint64_t> g_ctx_gen{0};
 
 static spec_status fail(spec_ctx *c, spec_status st, const char *fmt, ...) {
     char buf[512];
@@ -110,6 +117,7 @@ static spec_status fail(spec_ctx *c, spec_status st, const char *fmt, ...) {
         c->err = buf;
         t_err = buf;
         t_err_ctx = c;
+        t_err_gen = c->gen;
     } else {
         g_create_err = buf;
     }
@@ -192,8 +200,17 @@ const char *spec_status_string(spec_status st) {
 
 const char *spec_last_error(const spec_ctx *ctx) {
     if (!ctx) return g_create_err.c_str();
-    if (t_err_ctx == ctx) return t_err.c_str();  // this thread's own failure on a shared context
-    return ctx->err.c_str();
+    // this thread's own failure on a (possibly shared) context -- of THIS context, not of a destroyed one whose
+    // address a later spec_create was handed again
+    if (t_err_ctx == ctx && t_err_gen == ctx->gen) return t_err.c_str();
+    // another thread's failure: copied under the context's lock (that thread may be inside fail() right now), and the
+    // pointer handed out is this thread's own copy
+    spec_ctx *c = const_cast<spec_ctx *>(ctx);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    t_err = c->err;
+    t_err_ctx = ctx;
+    t_err_gen = ctx->gen;
+    return t_err.c_str();
 }
 
 spec_dtype spec_dtype_from_sigmf(const char *s) {
@@ -240,6 +257,7 @@ spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx *
                     prop.gcnArchName);
     spec_ctx *c = new (std::nothrow) spec_ctx;
     if (!c) return fail(nullptr, SPEC_ENOMEM, "spec_create: out of host memory");
+    c->gen = ++g_ctx_gen;
     c->device = device;
     c->flags = flags;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -497,7 +515,17 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         // "large_team" = 2, ONE guarded launch of the self-contained fall-back (spec_k_large.hip large_solo_kernel) that
         // runs only if a bounded wait of the team kernel timed out (grid not co-resident: a shared GPU).
         // "large_team" = 3 (tests): the team kernel is skipped and the abort word set, so the fall-back does the work.
-        const bool team = c->opt_large_team >= 2 || (c->opt_large_team == 1 && n_lines >= 64);
+        if (c->team_check_pending && c->team_sync && hipStreamQuery(c->stream) == hipSuccess) {
+            // the previous default-mode call has finished: did its team kernel give up?  (Looked at lazily -- the call
+            // itself stays asynchronous; its result was produced by the guarded fall-back either way.)  A context on a
+            // GPU where the persistent grid is not co-resident would otherwise spin to the 2 s limit in every call.
+            uint32_t aborted = 0;
+            if (hipMemcpy(&aborted, static_cast<uint32_t *>(c->team_sync) + large_team_abort_word(), 4, hipMemcpyDeviceToHost) == hipSuccess) {
+                c->team_check_pending = false;
+                if (aborted) c->team_disabled = true;
+            }
+        }
+        const bool team = c->opt_large_team >= 2 || (c->opt_large_team == 1 && n_lines >= 64 && !c->team_disabled);
         if (team) {
             uint32_t teams_max = 0;
             // line-sized slots of intermediate per team: they share the XCD's 4 MiB L2 with the input and output streams.
@@ -545,6 +573,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
                     if (aborted) return fail(c, SPEC_EDEVICE, "large-N team kernel: a bounded wait timed out (grid not co-resident)");
                 } else {  // one guarded launch: returns at once unless the abort word is set
+                    c->team_check_pending = c->opt_large_team == 1;
                     e = launch_spectro_large_solo(a, log2n, f64, tw1, tw2, c->scratch, solo_grid, c->stream, sync + large_team_abort_word());
                     if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N fall-back launch: %s", hipGetErrorString(e));
                 }
@@ -698,7 +727,10 @@ static spec_status waterfall_impl(spec_ctx *c, const void *iq, int iq_on_device,
     if (rec) {
         iq_on_device = 0;
         n_bytes = rec->bytes;
-        if (rec->map && !c->opt_rec_pread) {
+        struct stat now;  // a file that SHRANK since it was opened: touching the mapping past its end is SIGBUS for the
+                          // whole host process (a JVM included); pread zero-fills instead, so take that path for this call
+        const bool shrunk = fstat(rec->fd, &now) != 0 || (uint64_t)now.st_size < rec->header + rec->bytes;
+        if (rec->map && !c->opt_rec_pread && !shrunk) {
             // the file is mapped: its pages are ordinary pageable host memory and take the staged pipeline of
             // spec_waterfall as they are (measured: 93 GB/s over PCIe, both directions together, against 52 for
             // pread into the pinned ring, which pays one more copy out of the page cache)

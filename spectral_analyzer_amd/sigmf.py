@@ -110,6 +110,12 @@ class NativeRecording:
             self._svc._lib.spec_close_recording(self._h)
             self._h = None
 
+    def __del__(self):  # an unclosed handle would keep the descriptor and the whole-file mapping
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __enter__(self):
         return self
 

@@ -318,6 +318,8 @@ class SpectralService:
                     raise ValueError("out tensor has the wrong dtype/size")
             out_ptr = psd.data_ptr()
         else:
+            if out is not None:
+                raise ValueError("out= is for device-resident buffers; with host bytes the PSDs come back as a numpy array")
             psd = np.empty((int(n_psd), int(nfft)), dtype=np.float32)
             out_ptr = psd.ctypes.data
         self._check(self._lib.spec_welch_psd(

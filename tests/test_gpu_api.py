@@ -703,3 +703,21 @@ def test_waterfall_multi_equals_the_single_context_tile(svc, oracle, datatype, n
     finally:
         for p in peers:
             p.close()
+
+
+def test_last_error_is_not_inherited_from_a_destroyed_context(oracle):
+    """spec_last_error's per-thread cache is keyed on a per-context generation id: a context created after another was
+    destroyed -- quite possibly at the same address -- starts with an empty error text."""
+    import torch
+    iq = oracle.synth_iq("cf32_le", 1, 0, 4096)
+    for _ in range(8):
+        a = sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream)
+        with pytest.raises(ValueError, match="power of two"):
+            a.compute_waterfall(iq, 0, 1000, "cf32_le", 1)
+        addr = a._ctx.value
+        a.close()
+        b = sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream)
+        try:
+            assert b._lib.spec_last_error(b._ctx) == b"", (hex(addr), hex(b._ctx.value))
+        finally:
+            b.close()

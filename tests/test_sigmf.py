@@ -127,3 +127,19 @@ def test_recording_larger_than_2_gib(tmp_path, oracle, svc, dataset):
             svc.set_option("stage_chunk_mb", 64)
             svc.set_option("rec_pread", 0)
     os.unlink(data_path)
+
+
+@pytest.mark.gpu
+def test_a_recording_that_shrinks_after_it_was_opened_is_read_with_pread(tmp_path, oracle, svc):
+    """The library maps the whole data file.  If the file is truncated behind its back, touching the mapping past the
+    new end would be SIGBUS for the host process (a JVM included); the library re-stats before every call and reads with
+    pread for that call instead: bytes past the new end read as zero (flat -200 dB lines), nobody dies."""
+    nfft, lines = 256, 40
+    p, raw = write_pair(tmp_path, oracle, "ci16_le", lines * nfft, name="shrink")
+    rec = sigmf.load(p)
+    with sigmf.NativeRecording(svc, rec) as h:
+        full = h.waterfall(0, nfft, lines)
+        os.truncate(rec.data_path, 10 * nfft * 4)                  # 10 lines are left on disk
+        cut = h.waterfall(0, nfft, lines)
+        assert np.array_equal(cut[:10], full[:10])
+        assert np.abs(cut[10:] + 200.0).max() < 1e-3               # zeros -> 20 log10(1e-10) (SS:81) in fp32; the span is still "in range"

@@ -41,8 +41,8 @@ if "sizes" in which:
         spectro("cf32_le", n, n // 2, 30)
     spectro("cf32_le", 4096, 4096, 28, label="4096 hop=nfft (reference) cf32")
     spectro("cf32_le", 4096, 2048, 28, window=1, label="4096/2048 cf32 hann")
-    spectro("cu8", 4096, 2048, 28, label="4096/2048 cu8 (generic)")
-    spectro("cf32_be", 4096, 2048, 28, label="4096/2048 cf32_be (generic)")
+    spectro("cu8", 4096, 2048, 28, label="4096/2048 cu8")
+    spectro("cf32_be", 4096, 2048, 28, label="4096/2048 cf32_be")
 if "cfg5only" in which:
     spectro("cf64_le", 65536, 32768, 28, fmt=sa.OUT_DB20_F64, label="cfg5 65536/32768 cf64->f64 2^28")
 if "cfg5" in which:
