@@ -545,8 +545,10 @@ hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
 }
 
 // Instantiation matrix: register-reuse variants for hop = N/2 (50 % overlap) in every format, for
-// hop = N/4 (75 %) in cf32 / ci16 and in every Welch kernel; big-endian files and every other hop
-// take SH = 0 (the overlap then comes from L2).
+// hop = N/4 (75 %) in cf32 / ci16 and in every Welch kernel; every other hop takes SH = 0 (the overlap then
+// comes from L2).  Big-endian files: the 50 %-overlap spectrogram without a window has its register-reuse
+// variant too (round 3: the raw registers hold the file's bytes, the swap happens at decode; it was 49 % of
+// the peak re-reading the overlap from L2), everything else one SH = 0 variant per mode.
 // Welch always multiplies by a window table (all ones for the rectangular window).
 template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hipStream_t s) {
     constexpr int N = Plan2<L>::N, E = Plan2<L>::E;
@@ -554,7 +556,10 @@ template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hi
     if constexpr (WIDE) {  // big-endian files: one variant per mode (no register reuse), byte swap at decode
         if (a.be) {
             if constexpr (MODE == 1) return v2_launch1<L, KIND, 0, true, 1, true>(a, s);
-            else return a.win ? v2_launch1<L, KIND, 0, true, MODE, true>(a, s) : v2_launch1<L, KIND, 0, false, MODE, true>(a, s);
+            else if constexpr (MODE == 0) {
+                if (a.hop == N / 2 && !a.win) return v2_launch1<L, KIND, E / 2, false, 0, true>(a, s);
+                return a.win ? v2_launch1<L, KIND, 0, true, 0, true>(a, s) : v2_launch1<L, KIND, 0, false, 0, true>(a, s);
+            } else return a.win ? v2_launch1<L, KIND, 0, true, MODE, true>(a, s) : v2_launch1<L, KIND, 0, false, MODE, true>(a, s);
         }
     }
     if constexpr (MODE == 1) {
