@@ -543,6 +543,20 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         // inter-step twiddle W_N^(n2 k1), k1 = t1 + m T: W^(n2 t1) (W^(n2 T))^m, recurrence in fp64
         const uint32_t n2 = c0 + q1;
         const cx<double> w0 = twn[n2 * (uint32_t)t1], wstep = twn[n2 * (uint32_t)PA::T];
+        // fp32 lines: the eight twiddles W_N^(n2 (t1 + m T)) of a thread do not depend on the line -- straight from the
+        // table (n2 k1 < N), rounded to fp32 once, held in 16 registers the fp32 kernel has to spare: eight packed
+        // complex multiplications per line instead of sixteen fp64 ones and the conversions either way (round 3; the
+        // fp64 kernel keeps the recurrence: it has no 32 registers left)
+        constexpr bool TW_LINE_INV = sizeof(R) == 4 && !DENSE;
+        cx<R> wtw[TW_LINE_INV ? TE : 1];
+        if constexpr (TW_LINE_INV) {
+#pragma unroll
+            for (int m = 0; m < TE; ++m) {
+                const cx<double> w = twn[n2 * (uint32_t)(t1 + m * PA::T)];
+                wtw[m] = cx<R>{(R)w.x, (R)w.y};
+            }
+        }
+        (void)wtw;
         // rest of one line behind the first exchange: pass 2 and the inter-step twiddle
         PassTw<R, L1, WG> twr;
         constexpr bool TWREG = !DENSE;  // twiddles in registers where there are 256 of them
@@ -555,12 +569,17 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             if constexpr (TWREG) twr.pass2(v);
             else pass2<R, L1, WG>(v, t1, tab);
 #endif
-            cx<double> w = w0;
+            if constexpr (TW_LINE_INV) {
 #pragma unroll
-            for (int m = 0; m < TE; ++m) {
-                const cx<double> z = cmul(cx<double>{(double)v[m].x, (double)v[m].y}, w);
-                v[m] = cx<R>{(R)z.x, (R)z.y};
-                w = cmul(w, wstep);
+                for (int m = 0; m < TE; ++m) v[m] = cmul(v[m], wtw[m]);
+            } else {
+                cx<double> w = w0;
+#pragma unroll
+                for (int m = 0; m < TE; ++m) {
+                    const cx<double> z = cmul(cx<double>{(double)v[m].x, (double)v[m].y}, w);
+                    v[m] = cx<R>{(R)z.x, (R)z.y};
+                    w = cmul(w, wstep);
+                }
             }
         };
         if constexpr (DIRECT && LD::PIPE) {
@@ -804,7 +823,26 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                         db20_tab_n<HB>(z, s_dbt, d);
                     } else
 #endif
-                    {
+                    if constexpr (FMT == OUT_DB20_F32 && sizeof(R) == 4) {
+                        // fp32 lines: ONE range test per thread and half (as the packed family's epilogue, spec_v2.h): while
+                        // every |X|^2 is in [1e-4, 1e37), |X| + 1e-10 == |X| in fp32 and the value is 10 log10(p) -- one
+                        // v_log_f32 per bin; otherwise the exact form bin by bin (a bin inside the range gets the same value
+                        // either way).  Per bin the exact form alone is seven compares, a square root and the selects.
+                        float p[HB];
+#pragma unroll
+                        for (int m = 0; m < HB; ++m) p[m] = __builtin_fmaf(z[m].x, z[m].x, z[m].y * z[m].y);
+                        float lo = p[0], hi = p[0];
+#pragma unroll
+                        for (int m = 1; m < HB; ++m) { lo = fminf(lo, p[m]); hi = fmaxf(hi, p[m]); }
+                        constexpr float k10 = 3.01029995663981195f;  // 10 log10(2)
+                        if (lo > 1e-4f && hi < 1e37f) {  // a NaN fails the first test
+#pragma unroll
+                            for (int m = 0; m < HB; ++m) d[m] = k10 * __log2f(p[m]);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < HB; ++m) d[m] = db20(z[m]);
+                        }
+                    } else {
 #pragma unroll
                         for (int m = 0; m < HB; ++m) d[m] = (TO)bin_value<R, FMT>(z[m], s_dbt);
                     }
