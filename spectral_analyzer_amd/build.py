@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libspecgpu.so")
-SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_large.hip", "spec_k_team.hip", "spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v3d.hip", "spec_misc.hip", "spec_burst.hip"]
+SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_large.hip", "spec_k_team.hip", "spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2n.hip", "spec_k_v3d.hip", "spec_misc.hip", "spec_burst.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]

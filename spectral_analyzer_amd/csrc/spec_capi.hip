@@ -596,6 +596,20 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         }
         return SPEC_OK;
     }
+    if (!f64 && !d_sel && !c->opt_force_generic && v2n_applicable(log2n, a.kind, a.out_fmt, n_lines, hop, d_first)) {
+        // 64 / 128 points: wave-cooperative I/O around the packed FFT core (spec_k_v2n.hip)
+        uint64_t done = 0;
+        while (done < n_lines) {
+            const uint64_t rem = n_lines - done;
+            a.n_lines = rem < 0x40000000ull ? rem : 0x40000000ull;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_v2n_spectro(a, log2n, c->n_cu, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "spectrogram launch: %s", hipGetErrorString(e));
+            done += a.n_lines;
+        }
+        return SPEC_OK;
+    }
     const int lpw = plan_lpw(log2n);
     const bool v2 = !f64 && !c->opt_force_generic &&
                     v2_applicable(log2n, a.kind, a.be, a.out_fmt, n_lines, hop);

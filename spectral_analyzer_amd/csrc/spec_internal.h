@@ -80,6 +80,10 @@ hipError_t launch_v2_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream
 // fp64 member of the family (spec_v3d.h): 256 ... 4096 points, any sample format, fp64 arithmetic
 bool v3d_applicable(int log2n, int kind, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v3d_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream_t s);
+// 64- and 128-point lines (spec_k_v2n.hip): a wave works on 16 / 8 consecutive lines at a time, all global traffic in
+// 16-byte-per-lane pieces through its own LDS region; `first` = address of the first line's first byte (alignment)
+bool v2n_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop, const void *first);
+hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t s);
 bool v2_sel_applicable(int log2n, int kind, int be, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v2_spectro_sel(const WfArgs &w, int log2n, uint32_t run, const int32_t *sel, uint32_t out_stride,
                                  hipStream_t s);

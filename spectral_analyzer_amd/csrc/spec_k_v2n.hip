@@ -1,0 +1,211 @@
+// spec_k_v2n.hip -- spectrogram lines of 64 and 128 points (the low end of the reference's NFFT slider,
+// main-scene.fxml:129-132) on the packed-fp32 FFT core of spec_v2.h.
+//
+// With 16 points per thread such a line is only T = 4 or 8 lanes wide: left to itself every lane group would touch
+// global memory in 32- or 64-byte pieces (the family's own kernel was measured slower than the generic one for these
+// sizes).  Here a WAVE works on LB = 64 / T CONSECUTIVE lines at a time and does all global traffic together:
+//   * the block's input span ((LB - 1) hop + N samples, contiguous) is read with 16 bytes per lane, 1 KiB per
+//     instruction, and parked in the wave's own LDS region with one line-group's width of padding per line stride
+//     (the lanes of neighbouring lines then start in neighbouring banks); overlapping lines share it -- every
+//     input byte is requested once per block;
+//   * every lane group picks its line's 16 samples per thread out of the span (stride T, as the FFT wants them);
+//   * the transform is spec_v2.h's: radix 4 (or 8) in registers, ONE wave-local exchange through the same LDS
+//     region (no s_barrier anywhere in this kernel), radix 16 with its twiddles in registers, the family's epilogue;
+//   * the LB finished lines -- contiguous in the output -- are laid out in LDS (fftshift folded into the index) and
+//     leave with 16 bytes per lane, 1 KiB per instruction.
+// Any hop from 16 bytes' worth of samples up to N (the reference's own hop), any of the byte / 16-bit / float formats,
+// either byte order, optional window, dB or power output.
+#include "spec_v2.h"
+
+namespace specgpu {
+
+namespace {
+
+struct V2nArgs {
+    const uint8_t *iq;   // first byte of line 0
+    uint32_t n_lines, hop;
+    uint32_t pad_shift;  // floor(log2(hop * BPS)): one pad unit per 2^pad_shift bytes of span
+    const void *tw, *win;
+    float *out;
+    int out_fmt;
+};
+
+typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+#ifndef V2N_OCC
+#define V2N_OCC 3  // waves per SIMD asked of the register allocator (147 registers: no spills at 3)
+#endif
+
+// bytes of a wave's LDS region: the larger of the padded input span (maximised over every admissible hop), the
+// exchange buffer of the block's lines and their output staging
+template <int L, int BPS> constexpr int v2n_region_bytes() {
+    using PL = Plan2<L>;
+    constexpr int N = PL::N, T = PL::T, LB = 64 / T, PADU = T * BPS;
+    int in_max = 0;
+    for (int hop = (16 + BPS - 1) / BPS; hop <= N; ++hop) {
+        const int lb = hop * BPS;
+        int sh = 0;
+        while ((2 << sh) <= lb) ++sh;
+        const int span = 15 + (LB - 1) * lb + N * BPS;  // worst misalignment
+        const int padded = span + ((span >> sh) + 1) * PADU;
+        if (padded > in_max) in_max = padded;
+    }
+    const int ex = LB * PL::LINE * 8, out = LB * (N + 4) * 4;
+    int m = in_max > ex ? in_max : ex;
+    if (out > m) m = out;
+    return (m + 15) & ~15;
+}
+
+template <int L, int KIND, bool BE>
+__global__ __launch_bounds__(256, V2N_OCC) void v2n_kernel(const V2nArgs a) {
+    using PL = Plan2<L>;
+    using RW = Raw2<KIND>;
+    constexpr int N = PL::N, T = PL::T, E = PL::E, BPS = RW::BPS;
+    constexpr int LB = 64 / T;                      // lines per wave and block
+    constexpr int PADU = T * BPS;                   // pad unit: the bytes one line's lanes read per instruction
+    constexpr int OUT_STRIDE = N + 4;               // floats per staged output line: neighbouring lines 4 banks apart
+    constexpr int REGION = v2n_region_bytes<L, BPS>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char *region = smem + (size_t)wave * REGION;
+    const int t = lane % T, j = lane / T;           // this lane: butterfly index t of the block's line j
+    const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw);
+    v2f twl[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    const float *win = static_cast<const float *>(a.win);
+    float w[E];
+    if (win) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
+    }
+    const uint32_t n_blocks = (a.n_lines + LB - 1) / LB;
+    const uint32_t waves_total = gridDim.x * 4u, wave_id = blockIdx.x * 4u + (uint32_t)wave;
+    // consecutive blocks to one wave: the N - hop samples two blocks share are then re-read from L2 by the same CU
+    const uint32_t per_wave = (n_blocks + waves_total - 1) / waves_total;
+    const uint32_t b0 = wave_id * per_wave, b1 = b0 + per_wave < n_blocks ? b0 + per_wave : n_blocks;
+    const uint32_t line_bytes = a.hop * BPS, psh = a.pad_shift;
+    auto padded = [&](uint32_t x) -> uint32_t { return x + (x >> psh) * (uint32_t)PADU; };
+    // (Requesting the next block's span before the current block is transformed -- five 16-byte pieces per lane in
+    // flight behind the FFT -- was measured SLOWER, 47 % -> 38 % of the peak at 64 points: 168 registers with 10 dwords
+    // spilled, and a wait at the top of the loop that also drains the previous block's output stores.  Twelve waves
+    // per CU hide the latency better than one wave's prefetch does.)
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t l0 = b * LB;
+        const uint32_t nb = a.n_lines - l0 < (uint32_t)LB ? a.n_lines - l0 : (uint32_t)LB;  // valid lines of this block
+        // ---- input span -> LDS (16 bytes per lane; the first chunk starts at the 16-byte boundary below the span) ----
+        const uint8_t *first = a.iq + (uint64_t)l0 * line_bytes;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 15u);
+        const uint32_t span = mis + (nb - 1) * line_bytes + (uint32_t)N * BPS;  // bytes from the aligned base
+        const uint32_t chunks = (span + 15u) / 16u;
+        const vu4 *gsrc = reinterpret_cast<const vu4 *>(first - mis);
+        for (uint32_t c = (uint32_t)lane; c < chunks; c += 64u) {
+            const vu4 u = __builtin_nontemporal_load(gsrc + c);
+            *reinterpret_cast<vu4 *>(region + padded(16u * c)) = u;
+        }
+        v2_sync<L>();  // wave-local: the span is in LDS for every lane of this wave
+        // ---- this lane's 16 samples: x[j hop + t + m T] ----
+        v2f v[E];
+        const uint32_t base = mis + (uint32_t)j * line_bytes + (uint32_t)t * BPS;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const unsigned char *p = region + padded(base + (uint32_t)(m * T * BPS));
+            typename RW::type r;
+            if constexpr (BPS == 8) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(p);  // 4-byte aligned (checked by the host)
+                r = typename RW::type{q[0], q[1]};
+            } else if constexpr (BPS == 4) {
+                r = *reinterpret_cast<const uint32_t *>(p);
+            } else {
+                r = *reinterpret_cast<const uint16_t *>(p);
+            }
+            v[m] = RW::dec(BE ? RW::swap(r) : r);  // SMH:87-91 byte order
+        }
+        if (win) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};
+        }
+        v2_sync<L>();  // everybody has its samples: the region becomes the exchange buffer
+        v2_fft<L>(v, t, reinterpret_cast<v2f *>(region) + (size_t)j * PL::LINE, static_cast<const v2f *>(nullptr), twl);
+        float d[E];
+        constexpr bool BOUNDED = KIND != K_CF32;
+        if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, BOUNDED, E>(v, RW::SCALE, d);
+        else v2_epilogue<false, BOUNDED, E>(v, RW::SCALE, d);
+        v2_sync<L>();  // the exchange has been read: the region becomes the output staging
+        float *stage = reinterpret_cast<float *>(region);
+#pragma unroll
+        for (int m = 0; m < E; ++m)  // bin k = t + m T at column (k + N/2) mod N   (SS:78)
+            stage[j * OUT_STRIDE + ((t + m * T + N / 2) & (N - 1))] = d[m];
+        v2_sync<L>();
+        // ---- the block's nb lines are contiguous in the output: 16 bytes per lane ----
+        float *dst = a.out + (uint64_t)l0 * N;
+        const uint32_t out_chunks = nb * (uint32_t)(N / 4);
+        for (uint32_t c = (uint32_t)lane; c < out_chunks; c += 64u) {
+            const uint32_t row = c / (uint32_t)(N / 4), col = (c % (uint32_t)(N / 4)) * 4u;
+            const vu4 u = *reinterpret_cast<const vu4 *>(stage + row * OUT_STRIDE + col);
+            __builtin_nontemporal_store(u, reinterpret_cast<vu4 *>(dst) + c);
+        }
+        v2_sync<L>();  // the staging has been read: the next block's span may land
+    }
+}
+
+template <int L, int KIND, bool BE> hipError_t v2n_launch(const V2nArgs &a, int n_cu, hipStream_t s) {
+    using PL = Plan2<L>;
+    using RW = Raw2<KIND>;
+    constexpr int T = PL::T, LB = 64 / T;
+    constexpr int REGION = v2n_region_bytes<L, RW::BPS>();
+    constexpr size_t lds = (size_t)4 * REGION;
+    auto kern = v2n_kernel<L, KIND, BE>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t n_blocks = (a.n_lines + LB - 1) / LB;
+    // enough waves to fill the chip a few times over, consecutive blocks per wave
+    uint32_t wgs = (n_blocks + 3) / 4;
+    const uint32_t cap = (uint32_t)n_cu * 16u;
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int L, int KIND> hipError_t v2n_launch_be(const V2nArgs &a, int be, int n_cu, hipStream_t s) {
+    if constexpr (KIND == K_CF32 || KIND == K_CI16) {
+        if (be) return v2n_launch<L, KIND, true>(a, n_cu, s);
+    }
+    return v2n_launch<L, KIND, false>(a, n_cu, s);
+}
+
+template <int L> hipError_t v2n_launch_kind(const V2nArgs &a, int kind, int be, int n_cu, hipStream_t s) {
+    switch (kind) {
+    case K_CF32: return v2n_launch_be<L, K_CF32>(a, be, n_cu, s);
+    case K_CI16: return v2n_launch_be<L, K_CI16>(a, be, n_cu, s);
+    case K_CU8: return v2n_launch_be<L, K_CU8>(a, be, n_cu, s);
+    case K_CI8: return v2n_launch_be<L, K_CI8>(a, be, n_cu, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// 64 / 128 points, fp32 outputs, hop between 16 bytes' worth of samples and N, input aligned to min(4, bytes per sample)
+bool v2n_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop, const void *first) {
+    if (log2n != 6 && log2n != 7) return false;
+    if (kind != K_CF32 && kind != K_CI16 && kind != K_CU8 && kind != K_CI8) return false;
+    if (out_fmt != OUT_DB20_F32 && out_fmt != OUT_POW_F32) return false;
+    const uint32_t bps = kind == K_CF32 ? 8u : kind == K_CI16 ? 4u : 2u;
+    if (hop > (1u << log2n) || (uint64_t)hop * bps < 16u) return false;
+    if (reinterpret_cast<uintptr_t>(first) % (bps < 4u ? bps : 4u)) return false;
+    return n_lines > 0 && n_lines < (1ull << 31);
+}
+
+hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t s) {
+    V2nArgs a{};
+    a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.tw = w.tw; a.win = w.win;
+    a.out = static_cast<float *>(w.out); a.out_fmt = w.out_fmt;
+    uint32_t lb = w.hop * w.bps, sh = 0;
+    while ((2u << sh) <= lb) ++sh;
+    a.pad_shift = sh;
+    return log2n == 6 ? v2n_launch_kind<6>(a, w.kind, w.be, n_cu, s) : v2n_launch_kind<7>(a, w.kind, w.be, n_cu, s);
+}
+
+}  // namespace specgpu

@@ -36,6 +36,8 @@ template <int L> struct Plan2;
         static constexpr int PADSH = E == 32 ? 5 : 4; /* one pad element per 2^PADSH (narrow-stride exchanges) */ \
         static constexpr int LINE = N + (N >> PADSH) + (T < 32 ? 16 : 0); /* LDS elements per sub-line, pads included */ \
     };
+SPEC_PLAN2(6, 16, 2, 4, 16, 1, 1)   // 64 and 128 points: FFT core only; their kernel is spec_k_v2n.hip (wave-cooperative I/O)
+SPEC_PLAN2(7, 16, 2, 8, 16, 1, 1)
 SPEC_PLAN2(8, 16, 2, 16, 16, 1, 1)
 SPEC_PLAN2(9, 16, 3, 2, 16, 16, 1)
 SPEC_PLAN2(10, 16, 3, 4, 16, 16, 1)

@@ -246,3 +246,38 @@ def test_partial_last_workgroup_writes_nothing_past_the_tile(svc, oracle, case):
             assert bool((img[3:height * n_lines * 4:4] == 255).all())          # alpha of every pixel was written
     finally:
         svc.set_option("lines_per_wg", 0)
+
+
+# ---- 64- and 128-point lines: the wave-cooperative kernel (spec_k_v2n.hip) ------------------------------------------
+@pytest.mark.parametrize("nfft", [64, 128])
+@pytest.mark.parametrize("datatype,window", [("cf32_le", sa.WIN_RECT), ("cf32_be", sa.WIN_HANN), ("ci16_le", sa.WIN_HANN),
+                                             ("ci16_be", sa.WIN_RECT), ("cu8", sa.WIN_RECT), ("ci8", sa.WIN_HANN)])
+def test_short_lines_every_hop_and_tail(svc, oracle, nfft, datatype, window):
+    """The low end of the reference's NFFT slider (main-scene.fxml:129-132).  A wave works on 16 (8) consecutive lines
+    at a time through its own LDS region: every hop from 16 bytes' worth of samples up to nfft (the reference's own),
+    line counts that are not a multiple of the block (tail blocks), a start that is not 16-byte aligned, lines past the
+    end of the recording (-150, MC:994-998), power output; below 16 bytes per hop and above nfft the generic kernel runs."""
+    import torch
+    bps = oracle.bytes_per_sample(datatype)
+    for hop, n_lines, start_samples in ((nfft, 37, 0), (nfft // 2, 1000, 3), (nfft // 4, 129, 1), (max(16 // bps, 3), 70, 5),
+                                        (nfft - 7, 16, 2), (2 * nfft, 9, 0), (1, 33, 0)):
+        n = start_samples + (n_lines - 1) * hop + nfft
+        iq = oracle.synth_iq(datatype, seed=nfft + hop, first_sample=7, n_samples=n)
+        start = start_samples * bps
+        ref = oracle.waterfall(iq, start, datatype, nfft, hop, n_lines + 2, window)
+        got = svc.compute_waterfall(torch.from_numpy(iq).cuda(), start, nfft, datatype, n_lines + 2, hop=hop, window=window)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        assert np.all(got[n_lines:] == -150.0) and np.all(ref[n_lines:] == -150.0)
+        check_fp32(got[:n_lines], ref[:n_lines], nfft)
+    hop, n_lines = nfft // 2, 50
+    iq = oracle.synth_iq(datatype, 9, 0, (n_lines - 1) * hop + nfft)
+    p = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_POW_F32).astype(np.float64)
+    p_ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window, power=True)
+    assert np.abs(p - p_ref).max() <= 2e-6 * p_ref.max()
+    svc.set_option("force_generic", 1)              # and the generic kernel agrees (both paths stay covered)
+    try:
+        g = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window)
+    finally:
+        svc.set_option("force_generic", 0)
+    check_fp32(g, oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window), nfft)

@@ -35,7 +35,7 @@ if "cfg1" in which:
     spectro("cf32_le", 1024, 512, 20, label="cfg1 1024/512 cf32 2^20")
     spectro("cf32_le", 1024, 512, 28, label="1024/512 cf32 2^28")
 if "sizes" in which:
-    for n in (64, 256, 512, 1024, 2048):
+    for n in (64, 128, 256, 512, 1024, 2048):
         spectro("cf32_le", n, n // 2, 28)
     for n in (8192, 16384):  # long lines: 2^28 samples are only a few workgroup rounds
         spectro("cf32_le", n, n // 2, 30)
