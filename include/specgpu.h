@@ -127,6 +127,8 @@ void *spec_stream(const spec_ctx *ctx);
  *                     launch for any number of lines and no fall-back (the call then waits for the kernel and returns
  *                     SPEC_EDEVICE if one of its bounded waits timed out); 3 (tests) = the fall-back alone, as if the
  *                     persistent launch had timed out
+ *   "large_team_fake_abort" = 1 (tests)  the next default-mode large-N call behaves as if its persistent launch had timed out
+ *                     (a context that sees an abort takes the two-launch path from then on; setting "large_team" re-arms it)
  *   "large_ring" = 0..4  line-sized slots of intermediate per team of the persistent launch.  0 (default) = automatic:
  *                     2 for fp64 lines (the slots share the XCD's 4 MiB L2 with the input and output streams; 3 measured
  *                     5 % slower, 4 20 %), 3 for fp32 lines (slots of half the size: 3-4 % faster than 2)
@@ -141,6 +143,9 @@ void *spec_stream(const spec_ctx *ctx);
  *   "readahead_lines" = n slices spec_compute_magnitudes computes per launch once its calls walk a buffer
  *                     slice by slice (default 256; 0 or 1 = every call is its own launch) */
 spec_status spec_set_option(spec_ctx *ctx, const char *key, int64_t value);
+/* Current value of a knob of spec_set_option, or of the read-only state "large_team_disabled" (1 once a default-mode
+ * call of this context has seen its persistent large-N launch give up; "large_team" re-arms it). */
+spec_status spec_get_option(spec_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- datatype table ------------------------------------------------------ */
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "spec_sync": (_i32, [_vp]),
     "spec_stream": (_vp, [_vp]),
     "spec_set_option": (_i32, [_vp, _cp, C.c_int64]),
+    "spec_get_option": (_i32, [_vp, _cp, C.POINTER(C.c_int64)]),
     "spec_dtype_from_sigmf": (_i32, [_cp]),
     "spec_bytes_per_sample": (_u32, [_i32]),
     "spec_count_lines": (_u64, [_u64, _u64, _i32, _u32, _u32]),

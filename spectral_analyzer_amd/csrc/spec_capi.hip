@@ -70,6 +70,7 @@ struct spec_ctx {
     // the persistent large-N kernel: a launch whose abort word has not been looked at yet, and the verdict once a
     // bounded wait did time out on this context (shared / partitioned GPU): it is not tried again
     bool team_check_pending = false, team_disabled = false;
+    int64_t opt_team_fake_abort = 0;  // tests: the next default-mode call behaves as if its team kernel had timed out
     int n_cu = 256;
     // host-buffer pipeline (spec_waterfall): copy-in / copy-out streams and the events that order
     // them against the compute stream, created on first use
@@ -333,14 +334,35 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "rec_pread")) c->opt_rec_pread = value != 0;
     else if (!strcmp(key, "welch_two_pass")) c->opt_welch_two_pass = value != 0;
-    else if (!strcmp(key, "large_team")) c->opt_large_team = value < 0 ? 0 : (value > 3 ? 3 : value);
+    else if (!strcmp(key, "large_team")) {
+        c->opt_large_team = value < 0 ? 0 : (value > 3 ? 3 : value);
+        c->team_disabled = false;  // setting the knob gives the persistent launch another chance
+        c->team_check_pending = false;
+    }
     else if (!strcmp(key, "large_ring")) c->opt_large_ring = value < 0 ? 0 : (value > 4 ? 4 : value);
     else if (!strcmp(key, "large_wg")) c->opt_large_wg = value == 256 ? 256 : (value == 1024 ? 1024 : 512);
     else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
+    else if (!strcmp(key, "large_team_fake_abort")) c->opt_team_fake_abort = value != 0;
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
     else if (!strcmp(key, "readahead_lines")) { c->opt_readahead_lines = value < 0 ? 0 : value; c->ra.n = 0; }
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
     return SPEC_OK;
+}
+
+spec_status spec_get_option(spec_ctx *c, const char *key, int64_t *value) {
+    if (!c) return SPEC_EINVAL;
+    Enter g(c);
+    if (!key || !value) return fail(c, SPEC_EINVAL, "spec_get_option: null argument");
+    struct { const char *k; int64_t v; } tab[] = {
+        {"force_generic", c->opt_force_generic}, {"lines_per_wg", c->opt_lines_per_wg}, {"large_chunk_mb", c->opt_large_chunk_mb},
+        {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass},
+        {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg},
+        {"large_block", c->opt_large_block}, {"render_fused", c->opt_render_fused}, {"readahead_lines", c->opt_readahead_lines},
+        {"large_team_fake_abort", c->opt_team_fake_abort}, {"large_team_disabled", c->team_disabled ? 1 : 0},
+    };
+    for (const auto &e : tab)
+        if (!strcmp(key, e.k)) { *value = e.v; return SPEC_OK; }
+    return fail(c, SPEC_EINVAL, "spec_get_option: unknown key '%s'", key);
 }
 
 }  // extern "C"
@@ -519,8 +541,9 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             // the previous default-mode call has finished: did its team kernel give up?  (Looked at lazily -- the call
             // itself stays asynchronous; its result was produced by the guarded fall-back either way.)  A context on a
             // GPU where the persistent grid is not co-resident would otherwise spin to the 2 s limit in every call.
-            uint32_t aborted = 0;
-            if (hipMemcpy(&aborted, static_cast<uint32_t *>(c->team_sync) + large_team_abort_word(), 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint32_t aborted = 0;  // on the context's own (idle) stream: no null-stream synchronisation with the host's other streams
+            if (hipMemcpyAsync(&aborted, static_cast<uint32_t *>(c->team_sync) + large_team_abort_word(), 4, hipMemcpyDeviceToHost,
+                               c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) {
                 c->team_check_pending = false;
                 if (aborted) c->team_disabled = true;
             }
@@ -551,7 +574,9 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                 a.n_lines = nl;
                 a.iq = d_first + done * (uint64_t)hop * a.bps;
                 a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
-                if (c->opt_large_team == 3) {
+                const bool fake_abort = c->opt_large_team == 3 || (c->opt_large_team == 1 && c->opt_team_fake_abort);
+                c->opt_team_fake_abort = 0;
+                if (fake_abort) {
                     HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sync + large_team_abort_word()), 1, 1, c->stream));
                 } else {
                     e = launch_spectro_team(a, log2n, f64, tw1, tw2, c->team_scratch, ring, sync, c->n_cu,

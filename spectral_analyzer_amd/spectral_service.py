@@ -172,6 +172,12 @@ class SpectralService:
         """Tuning / testing knobs of ``spec_set_option`` (include/specgpu.h)."""
         self._check(self._lib.spec_set_option(self._ctx, key.encode(), int(value)))
 
+    def get_option(self, key: str) -> int:
+        """``spec_get_option``: a knob's current value, or the read-only state ``large_team_disabled``."""
+        v = C.c_int64(0)
+        self._check(self._lib.spec_get_option(self._ctx, key.encode(), C.byref(v)))
+        return int(v.value)
+
     @property
     def stream(self) -> int:
         return int(self._lib.spec_stream(self._ctx) or 0)

@@ -153,6 +153,41 @@ def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nf
         svc.set_option("large_team", 1)
 
 
+def test_a_context_stops_trying_the_team_kernel_after_one_abort(oracle):
+    """The default mode never waits for the team kernel's abort word (the call stays asynchronous; the guarded fall-back
+    repairs the result).  The context looks at the PREVIOUS call's word at its next large-N call, once its stream is
+    idle, and after one abort takes the two-launch path instead of spinning to the 2 s limit in every call; setting the
+    "large_team" knob re-arms the team kernel.  The abort is simulated ("large_team_fake_abort")."""
+    import torch
+    s = sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream)
+    try:
+        datatype, nfft, hop, n_lines = "cf64_le", 16384, 8192, 70
+        iq = torch.from_numpy(oracle.synth_iq(datatype, 13, 0, (n_lines - 1) * hop + nfft)).cuda()
+
+        def run():   # (the context has a stream of its own: wait for it before anything on torch's stream reads the tile)
+            o = s.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=sa.OUT_POW_F64)
+            s.synchronize()
+            return o.clone()
+        def same(a, b):
+            return float((a - b).abs().max() / b.abs().max()) <= 1e-12
+        s.set_option("large_team", 0); two = run()
+        s.set_option("large_team", 1)
+        assert same(run(), two) and s.get_option("large_team_disabled") == 0    # default mode: the team kernel, no complaint
+        assert same(run(), two) and s.get_option("large_team_disabled") == 0
+        s.set_option("large_team_fake_abort", 1)
+        assert same(run(), two)                            # "timed out": the guarded fall-back wrote the lines
+        assert s.get_option("large_team_disabled") == 0    # ... and nobody has looked at the abort word yet
+        assert same(run(), two)                            # looked at here, at the next call's entry
+        assert s.get_option("large_team_disabled") == 1    # two-launch path from now on
+        assert same(run(), two) and s.get_option("large_team_disabled") == 1
+        s.set_option("large_team", 1)                      # the knob re-arms the persistent launch
+        assert s.get_option("large_team_disabled") == 0 and same(run(), two)
+        with pytest.raises(ValueError):
+            s.get_option("no_such_knob")
+    finally:
+        s.close()
+
+
 # ---- team kernel vs two-launch path, EVERY value of a full-size output (the hand-off between workgroups rests on the
 # hardware's L2 behaviour: a stale tile would be a rare wrong 16-column stripe, which sampled checks miss) -------------
 @pytest.mark.parametrize("datatype,fmt,tol", [("cf64_le", sa.OUT_POW_F64, 1e-12), ("cf32_le", sa.OUT_POW_F32, 4e-6)])
