@@ -464,7 +464,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
         if constexpr (MODE == 1) {
             if (line < my_lines) {
 #pragma unroll
-                for (int m = 0; m < E; ++m) acc[m] += pk_norm(v[m]);
+                for (int m = 0; m < E; ++m)  // two chained FMAs per point (as a sum of pk_norm: multiply, FMA and an add)
+                    acc[m] = __builtin_fmaf(v[m].x, v[m].x, __builtin_fmaf(v[m].y, v[m].y, acc[m]));
             }
         } else {
             float d[E];

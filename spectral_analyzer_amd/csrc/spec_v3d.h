@@ -111,7 +111,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
         if constexpr (MODE == 1) {
             if (line < my_lines) {
 #pragma unroll
-                for (int m = 0; m < E; ++m) acc[m] += pk_norm(v[m]);
+                for (int m = 0; m < E; ++m) acc[m] = __builtin_fma(v[m].x, v[m].x, __builtin_fma(v[m].y, v[m].y, acc[m]));  // two chained FMAs per point
             }
             continue;
         }
