@@ -276,3 +276,74 @@ def test_render_decimation_matches_numpy(oracle):
     n = np.clip((wf[:, bins] - oracle.display_conversion(fs, N) + 120.0) / 100.0, 0, 1)
     ref = np.floor(n.astype(np.float32).astype(np.float64) * 255.0 + 0.5).astype(np.uint8)   # [W, H]
     assert np.array_equal(img[::-1, :, 0].T, ref) and np.all(img[..., 3] == 255)
+
+
+def _cm3_transform_py(re, im):
+    """A second, independent transcription of commons-math3 3.6.1's FastFourierTransformer.transformInPlace (FORWARD,
+    STANDARD) in plain Python floats (IEEE doubles, no fused multiply-add) -- same published steps as
+    oracle/spec_oracle.c::cm3_transform_in_place, written separately, so that a slip of the pen in either shows up as a
+    bit difference."""
+    import math
+    n = len(re)
+    if n == 1:
+        return
+    if n == 2:
+        re[0], re[1] = re[0] + re[1], re[0] - re[1]
+        im[0], im[1] = im[0] + im[1], im[0] - im[1]
+        return
+    j = 0                                                   # bitReversalShuffle2
+    for i in range(n):
+        if i < j:
+            re[i], re[j] = re[j], re[i]
+            im[i], im[j] = im[j], im[i]
+        k = n >> 1
+        while k <= j and k > 0:
+            j -= k
+            k >>= 1
+        j += k
+    for i0 in range(0, n, 4):                               # 4-term DFT
+        i1, i2, i3 = i0 + 1, i0 + 2, i0 + 3
+        r0, s0, r1, s1, r2, s2, r3, s3 = re[i0], im[i0], re[i2], im[i2], re[i1], im[i1], re[i3], im[i3]
+        re[i0] = r0 + r1 + r2 + r3
+        im[i0] = s0 + s1 + s2 + s3
+        re[i1] = r0 - r2 + (s1 - s3)
+        im[i1] = s0 - s2 + (r3 - r1)
+        re[i2] = r0 - r1 + r2 - r3
+        im[i2] = s0 - s1 + s2 - s3
+        re[i3] = r0 - r2 + (s3 - s1)
+        im[i3] = s0 - s2 + (r1 - r3)
+    last_n0, last_log = 4, 2
+    while last_n0 < n:
+        n0, log_n0 = last_n0 << 1, last_log + 1
+        a = 2.0 * math.pi / 2.0 ** log_n0                   # the library's W_SUB_N tables: cos / -sin at this double
+        wr, wi = math.cos(a), -math.sin(a)
+        for even in range(0, n, n0):
+            odd = even + last_n0
+            cr, ci = 1.0, 0.0
+            for r in range(last_n0):
+                gr, gi, hr, hi = re[even + r], im[even + r], re[odd + r], im[odd + r]
+                re[even + r] = gr + cr * hr - ci * hi
+                im[even + r] = gi + cr * hi + ci * hr
+                re[odd + r] = gr - (cr * hr - ci * hi)
+                im[odd + r] = gi - (cr * hi + ci * hr)
+                cr, ci = cr * wr - ci * wi, cr * wi + ci * wr
+        last_n0, last_log = n0, log_n0
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 64, 256, 1024, 4096])
+def test_cm3_c_and_python_transcriptions_agree_bit_for_bit(oracle, n):
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=n) + 1j * rng.normal(size=n)
+    re, im = list(x.real), list(x.imag)
+    _cm3_transform_py(re, im)
+    got = oracle.fft_forward(x, oracle.FFT_CM3)
+    assert np.array_equal(got.real, np.array(re)) and np.array_equal(got.imag, np.array(im))
+    # Complex.abs() the same way
+    for a, b in zip(re[:32], im[:32]):
+        if abs(a) < abs(b):
+            q = a / b
+            ref = abs(b) * np.sqrt(1 + q * q) if b != 0.0 else abs(a)
+        else:
+            q = b / a if a != 0.0 else 0.0
+            ref = abs(a) * np.sqrt(1 + q * q) if a != 0.0 else abs(b)
+        assert oracle.complex_abs(a, b) == ref
