@@ -111,3 +111,44 @@ def test_random_burst_requests_match_oracle(svc, oracle, seed):
         assert np.abs(mag[ok] - ref_mag[ok]).max(initial=0.0) <= 1e-9, tag
         ref_frq = oracle.inst_freq_trace(dn[0], dn[1], alpha, fs, 1e9)
         assert frq.shape == ref_frq.shape and np.abs(frq - ref_frq).max(initial=0.0) <= 1e-9 * fs + 1e-6, tag
+
+
+def _welch_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        nfft = 1 << int(rng.choice([4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]))
+        hop = int(rng.choice([nfft, nfft // 2, nfft // 4, int(rng.integers(1, 2 * nfft + 1))]))
+        n_seg = int(rng.integers(1, max(2, min(40, (1 << 17) // nfft))))
+        n_psd = int(rng.integers(1, 4))
+        yield (str(rng.choice(DTYPES)), nfft, hop, n_seg, n_psd, int(rng.integers(0, 30)), int(rng.integers(0, 2)),
+               int(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(1, 1 << 30)))
+
+
+@pytest.mark.parametrize("seed", [4, 5, 6])
+def test_random_welch_requests_match_oracle(svc, oracle, seed):
+    """The Welch entry (ADC:303-313 call shape, batched) over random datatype / nfft / hop / segments / batch / start /
+    window / scaling, host or device input: linear within 5e-6 of the PSD's peak (fp32 sums; 1e-9 for the fp64 family that
+    cf64 and big-endian inputs take), dB within 2e-3 on bins above 1e-3 of the peak."""
+    import torch
+    fs = 1.0e6
+    for dt, nfft, hop, n_seg, n_psd, start, window, scaling, on_device, s in _welch_cases(seed, 40):
+        bps = oracle.bytes_per_sample(dt)
+        per = (n_seg - 1) * hop + nfft + int(s % 7)          # a few samples between the PSDs' spans
+        iq = oracle.synth_iq(dt, s, 0, start + per * n_psd)
+        tag = (dt, nfft, hop, n_seg, n_psd, start, window, scaling, on_device)
+        buf = torch.from_numpy(iq).cuda() if on_device else iq
+        res = []
+        for db in (False, True):
+            _, p = svc.welch_psd(buf, start * bps, dt, fs, nfft=nfft, hop=hop, n_seg=n_seg, window=window, scaling=scaling,
+                                 n_psd=n_psd, psd_stride_bytes=per * bps, db=db)
+            if on_device:
+                torch.cuda.synchronize()
+                p = p.cpu().numpy()
+            res.append(np.asarray(p, dtype=np.float64))
+        assert res[0].shape == (n_psd, nfft), tag
+        for b in range(n_psd):
+            _, ref = oracle.welch_psd(iq, (start + b * per) * bps, dt, nfft, hop, n_seg, window, scaling, fs)
+            _, ref_db = oracle.welch_psd(iq, (start + b * per) * bps, dt, nfft, hop, n_seg, window, scaling, fs, db=True)
+            assert np.abs(res[0][b] - ref).max() <= 5e-6 * ref.max(), tag
+            strong = ref >= 1e-3 * ref.max()
+            assert np.abs(res[1][b] - ref_db)[strong].max() <= 2e-3, tag
