@@ -145,3 +145,40 @@ def test_psd_of_a_device_resident_burst(svc, edc, oracle):
     f, p = oracle.welch_psd(raw.view(np.uint8), 0, "cf64_le", 8192, 4096, (host.shape[1] - 8192) // 4096 + 1, fs=2.5e5)
     # the dialog's row is dB (ADC:319-328, 612, 675, 751): 2e-6 relative in power = 8.7e-6 dB
     assert np.allclose(on_dev[0], f) and np.abs(on_dev[1] - 10 * np.log10(p + 1e-20)).max() <= 1e-5
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_random_burst_requests_match_oracle(svc, edc, oracle, seed):
+    """The whole chain on random requests: datatype, start, count, frequency offset, decimation (both filters, including
+    factors past the one-pass FIR kernel's span) and smoothing factor -- reader bit for bit, the rest to the tolerances above."""
+    rng = np.random.default_rng(seed)
+    for _ in range(25):
+        dt = str(rng.choice(DTYPES))
+        count = int(rng.choice([1, 2, 3, int(rng.integers(4, 300)), int(rng.integers(300, 60000))]))
+        start = int(rng.integers(0, 100))
+        down = int(rng.choice([1, 2, 3, int(rng.integers(4, 40)), int(rng.integers(40, 320))]))
+        fast = bool(rng.integers(0, 2))
+        f_off = float(rng.uniform(-0.5, 0.5))
+        alpha = float(rng.choice([0.0, 1.0, rng.uniform(0.001, 0.999)]))
+        tag = (dt, count, start, down, fast, f_off, alpha)
+        iq = oracle.synth_iq(dt, int(rng.integers(1, 1 << 30)), 0, start + count + 3)
+        re, im = oracle.extract_iq(iq, start, count, dt)
+        got = edc.extract_iq(iq, start, count, dt)
+        assert np.array_equal(got[0], re) and np.array_equal(got[1], im), tag
+        ref = oracle.down_convert(re, im, f_off, down, 0 if fast else 1)
+        y = edc.extract_and_down_convert(iq, start, count, dt, f_off, down, fast)
+        assert y.shape == (2, count // down), tag
+        if y.shape[1] == 0:
+            continue
+        m = max(np.abs(re).max(), np.abs(im).max(), 1e-300)
+        assert np.abs(y[0] - ref[0]).max() <= 1e-12 * m and np.abs(y[1] - ref[1]).max() <= 1e-12 * m, tag
+        data = np.stack([ref[0], ref[1]])
+        mag, mref = svc.magnitude_trace(data, alpha), oracle.magnitude_trace(ref[0], ref[1], alpha)
+        v = 10 ** (mref / 20)
+        ok = v >= 1e-9 * max(v.max(), 1e-300)
+        assert ok.sum() == 0 or np.abs(mag[ok] - mref[ok]).max() <= 1e-9, tag
+        fs = 1e6 / down
+        frq = svc.inst_freq_trace(data, alpha, fs, 1e8)
+        assert frq.shape == (data.shape[1] - 1,), tag
+        if frq.size:
+            assert np.abs(frq - oracle.inst_freq_trace(ref[0], ref[1], alpha, fs, 1e8)).max() <= 1e-9 * fs, tag
