@@ -152,3 +152,33 @@ def test_random_welch_requests_match_oracle(svc, oracle, seed):
             assert np.abs(res[0][b] - ref).max() <= 5e-6 * ref.max(), tag
             strong = ref >= 1e-3 * ref.max()
             assert np.abs(res[1][b] - ref_db)[strong].max() <= 2e-3, tag
+
+
+@pytest.mark.parametrize("seed", [10, 11])
+def test_random_redraws_match_the_restated_renderer(svc, oracle, seed):
+    """One redraw (MC:980-999 lines, MC:1261-1291 image) on random requests: the fused form (compact tile) gives the very
+    pixels of the two-pass form, and both are the restated Java renderer applied to the GPU's own dB tile -- any datatype,
+    size, hop, canvas, dB range and colour map, columns past the end of the buffer included."""
+    rng = np.random.default_rng(seed)
+    for _ in range(30):
+        dt = str(rng.choice(DTYPES))
+        nfft = 1 << int(rng.choice([6, 7, 8, 9, 10, 11, 12, 13]))
+        hop = int(rng.choice([nfft, nfft // 2, int(rng.integers(1, 2 * nfft + 1))]))
+        width = int(rng.integers(1, 120))
+        height = int(rng.choice([1, int(rng.integers(2, nfft + 1)), int(rng.integers(nfft, 2 * nfft + 2))]))
+        past = int(rng.integers(0, 4))                      # columns that run past the end: -150 dB
+        n = max(width - past - 1, 0) * hop + nfft
+        iq = oracle.synth_iq(dt, int(rng.integers(1, 1 << 30)), 0, n)
+        fs, lo = float(rng.uniform(1e3, 1e8)), float(rng.uniform(-160.0, -40.0))
+        hi = lo + float(rng.uniform(1.0, 120.0))
+        cmap = int(rng.choice([sa.CMAP_GRAYSCALE, sa.CMAP_HEATMAP]))
+        tag = (dt, nfft, hop, width, height, past, fs, lo, hi, cmap)
+        fused = svc.waterfall_render(iq, 0, nfft, dt, width, height, fs, min_db=lo, max_db=hi, colormap=cmap, hop=hop)
+        svc.set_option("render_fused", 0)
+        try:
+            plain = svc.waterfall_render(iq, 0, nfft, dt, width, height, fs, min_db=lo, max_db=hi, colormap=cmap, hop=hop)
+        finally:
+            svc.set_option("render_fused", 1)
+        assert fused.shape == (height, width, 4) and np.array_equal(fused, plain), tag
+        tile = svc.compute_waterfall(iq, 0, nfft, dt, width, hop=hop)
+        assert np.array_equal(fused, oracle.render_spectrogram(tile.astype(np.float64), height, fs, lo, hi, cmap)), tag
