@@ -182,3 +182,39 @@ def test_random_redraws_match_the_restated_renderer(svc, oracle, seed):
         assert fused.shape == (height, width, 4) and np.array_equal(fused, plain), tag
         tile = svc.compute_waterfall(iq, 0, nfft, dt, width, hop=hop)
         assert np.array_equal(fused, oracle.render_spectrogram(tile.astype(np.float64), height, fs, lo, hi, cmap)), tag
+
+
+@pytest.mark.parametrize("seed", [12, 13])
+def test_random_sharded_requests_equal_the_single_context_tile(svc, oracle, seed):
+    """spec_waterfall_multi over one to four contexts (all on device 0 on the one-GPU box) on random requests -- datatype, size,
+    hop, start, line count (also fewer lines than contexts), lines past the end, window, output format, host or device tile,
+    number of pieces -- is the single-context tile bit for bit."""
+    import torch
+    rng = np.random.default_rng(seed)
+    peers = [sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream) for _ in range(3)]
+    try:
+        for _ in range(25):
+            dt = str(rng.choice(DTYPES))
+            nfft = 1 << int(rng.choice([6, 8, 9, 10, 11, 12, 13]))
+            hop = int(rng.choice([nfft, nfft // 2, nfft // 4, int(rng.integers(1, 2 * nfft + 1))]))
+            n_lines = int(rng.choice([1, 2, 3, int(rng.integers(4, max(5, min(400, (1 << 18) // nfft))))]))
+            extra, start = int(rng.integers(0, 3)), int(rng.integers(0, 20))
+            window = int(rng.integers(0, 2))
+            fmt = int(rng.choice([sa.OUT_DB20_F32, sa.OUT_POW_F32, sa.OUT_DB20_F64]))
+            n_ctx = int(rng.integers(1, 5))
+            bps = oracle.bytes_per_sample(dt)
+            iq = oracle.synth_iq(dt, int(rng.integers(1, 1 << 30)), 0, start + (n_lines - 1) * hop + nfft)
+            tag = (dt, nfft, hop, n_lines, extra, start, window, fmt, n_ctx)
+            one = svc.compute_waterfall(iq, start * bps, nfft, dt, n_lines + extra, hop=hop, window=window, out_fmt=fmt)
+            services = [svc] + peers[:n_ctx - 1]
+            if rng.integers(0, 2):
+                got = sa.compute_waterfall_multi(services, iq, start * bps, nfft, dt, n_lines + extra, hop=hop, window=window, out_fmt=fmt)
+            else:
+                out = torch.full((n_lines + extra, nfft), float("nan"), dtype=torch.from_numpy(one[:1]).dtype, device="cuda")
+                sa.compute_waterfall_multi(services, iq, start * bps, nfft, dt, n_lines + extra, hop=hop, window=window, out_fmt=fmt,
+                                           out=out, n_chunks=int(rng.integers(0, 7)))
+                got = out.cpu().numpy()
+            assert got.dtype == one.dtype and np.array_equal(got, one), tag
+    finally:
+        for p in peers:
+            p.close()
