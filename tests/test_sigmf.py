@@ -143,3 +143,41 @@ def test_a_recording_that_shrinks_after_it_was_opened_is_read_with_pread(tmp_pat
         cut = h.waterfall(0, nfft, lines)
         assert np.array_equal(cut[:10], full[:10])
         assert np.abs(cut[10:] + 200.0).max() < 1e-3               # zeros -> 20 log10(1e-10) (SS:81) in fp32; the span is still "in range"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [14, 15])
+def test_random_redraws_of_recordings_equal_the_buffer_path(tmp_path, oracle, svc, seed):
+    """Random SigMF pairs (datatype, header bytes, length) and random redraws (scroll offset, size, hop, canvas width,
+    window, output format): the library's own file reader -- whole-file mapping, and the pread ring of `rec_pread` -- gives
+    the very tile of the buffer path on the same bytes (which the other tests pin to the oracle), lines past the end -150;
+    the single-line call likewise."""
+    rng = np.random.default_rng(seed)
+    dtypes = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "cf64_be"]
+    for k in range(6):
+        dt = str(rng.choice(dtypes))
+        n = int(rng.integers(1, 200000))
+        header = int(rng.choice([0, 1, 44, int(rng.integers(2, 5000))]))
+        p, raw = write_pair(tmp_path, oracle, dt, n, header=header, seed=int(rng.integers(1, 1 << 30)), name="r%d_%d" % (seed, k))
+        rec = sigmf.load(p)
+        for pread in (0, 1):
+            svc.set_option("rec_pread", pread)
+            try:
+                with rec.open_native(svc) as nat:
+                    assert nat.n_bytes == raw.size
+                    for _ in range(5):
+                        nfft = 1 << int(rng.choice([6, 8, 10, 12, 13]))
+                        hop = int(rng.choice([nfft, nfft // 2, int(rng.integers(1, 2 * nfft + 1))]))
+                        off = int(rng.integers(0, n + 5))
+                        width = int(rng.integers(1, 60))
+                        window = int(rng.integers(0, 2))
+                        fmt = int(rng.choice([0, 1, 2]))                     # dB f32, |X|^2 f32, dB f64
+                        tag = (dt, n, header, pread, nfft, hop, off, width, window, fmt)
+                        ref = svc.compute_waterfall(raw, off * rec.bytes_per_sample, nfft, dt, width, hop=hop, window=window, out_fmt=fmt)
+                        got = nat.waterfall(off, nfft, width, hop=hop, window=window, out_fmt=fmt)
+                        assert got.dtype == ref.dtype and np.array_equal(got, ref), tag
+                        if off * rec.bytes_per_sample + nfft * rec.bytes_per_sample <= raw.size:
+                            assert np.array_equal(nat.compute_magnitudes(off * rec.bytes_per_sample, nfft),
+                                                  svc.compute_magnitudes(raw, off * rec.bytes_per_sample, nfft, dt, rec.big_endian)), tag
+            finally:
+                svc.set_option("rec_pread", 0)
