@@ -218,3 +218,30 @@ def test_random_sharded_requests_equal_the_single_context_tile(svc, oracle, seed
     finally:
         for p in peers:
             p.close()
+
+
+@pytest.mark.parametrize("seed", [16, 17])
+def test_random_psd_dialog_calls_match_scipy(svc, seed):
+    """calculatePsdWelch(double[2][N], fs, nfft) (ADC:303-313) on random bursts: nfft = the burst length for short bursts (the
+    dialog's rule, any integer) or any length up to 8192, explicit hop; against scipy.signal.welch -- an oracle that shares no
+    code with the build -- to 1e-9 of the PSD's peak (fp64 end to end), host and device input."""
+    import scipy.signal
+    import torch
+    rng = np.random.default_rng(seed)
+    for _ in range(14):
+        n = int(rng.choice([2, 3, int(rng.integers(4, 600)), int(rng.integers(600, 8192)), int(rng.integers(8192, 40000))]))
+        nfft = n if (n < 8192 and rng.integers(0, 2)) else int(rng.choice([min(n, 8192), int(rng.integers(2, min(n, 8192) + 1)),
+                                                                         1 << int(rng.integers(1, int(np.log2(min(n, 8192))) + 1))]))
+        hop = int(rng.choice([max(nfft // 2, 1), int(rng.integers(1, nfft + 1))]))
+        fs = float(rng.uniform(1e3, 1e8))
+        scaling = int(rng.integers(0, 2))
+        x = rng.normal(size=n) + 1j * rng.normal(size=n) + 2 * np.exp(2j * np.pi * float(rng.uniform(-0.5, 0.5)) * np.arange(n))
+        data = np.stack([x.real, x.imag])
+        tag = (n, nfft, hop, fs, scaling)
+        arg = torch.from_numpy(data).cuda() if rng.integers(0, 2) else data
+        out = svc.calculate_psd_welch(arg, fs, nfft, hop=hop, scaling=scaling, db=False)
+        f_ref, p_ref = scipy.signal.welch(x, fs, window="hann", nperseg=nfft, noverlap=nfft - hop, nfft=nfft, detrend=False,
+                                          return_onesided=False, scaling="density" if scaling == sa.PSD_DENSITY else "spectrum")
+        assert out.shape == (2, nfft), tag
+        assert np.allclose(out[0], np.fft.fftshift(f_ref), rtol=1e-12, atol=1e-9 * fs), tag
+        assert np.abs(out[1] - np.fft.fftshift(p_ref)).max() <= 1e-9 * p_ref.max(), tag
