@@ -310,6 +310,25 @@ spec_status spec_welch_psd(spec_ctx *ctx, const void *iq, int iq_on_device, uint
                            spec_window window, spec_psd_scaling scaling, double fs, int db,
                            double *freq_out, float *psd_out, int out_on_device);
 
+/* The batch of spec_welch_psd over several contexts -- what a single-process host (the reference is one JVM,
+ * JavaFxApplication.java:31-54) uses to spread a batch of PSDs over the GPUs of a node; SURVEY 8e, Welch side.
+ * The PSDs of a batch are independent: context r computes the contiguous range spec_shard_lines(n_psd, n_ctx, r)
+ * of them on its own device, one host thread per context inside the call, no exchange on the data path (the
+ * segments of ONE PSD are not split: at the dialog's sizes a PSD is microseconds of work).  Argument meaning and
+ * error behaviour are spec_welch_psd's; the result is what ONE context returns for the same batch -- bit for bit while
+ * both take the same form of the kernel, to the rounding of the fp32 segment sums otherwise (a context sums a batch
+ * of >= two PSDs per CU in one pass, smaller ones in runs of <= 64 segments; both within the 5e-6 of the parity tests).
+ * iq_on_device == 0: iq[0] is the host buffer (n_bytes[0] bytes, start_byte as in spec_welch_psd); every context
+ *   stages the span of its own PSDs.  iq_on_device != 0: iq[r] is memory on ctx[r]'s device whose byte 0 is the first
+ *   byte of shard r's first PSD (n_bytes[r] bytes; start_byte is ignored); NULL for a shard without PSDs.
+ * psd_out: n_psd x nfft floats in host memory, or (out_on_device != 0) on ctx[0]'s device -- the peers send their
+ *   rows there with hipMemcpyPeerAsync.  freq_out as in spec_welch_psd.  Complete on return. */
+spec_status spec_welch_psd_multi(spec_ctx *const *ctx, uint32_t n_ctx, const void *const *iq, int iq_on_device,
+                                 const uint64_t *n_bytes, uint64_t start_byte, uint64_t psd_stride_bytes,
+                                 uint32_t n_psd, spec_dtype dt, uint32_t nfft, uint32_t hop, uint32_t n_seg,
+                                 spec_window window, spec_psd_scaling scaling, double fs, int db,
+                                 double *freq_out, float *psd_out, int out_on_device);
+
 /* The same estimate for the exact argument shape of the reference call
  *   PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft)
  * (AnalysisDialogController.java:308-312): planar doubles data[0] = I, data[1] = Q as produced by

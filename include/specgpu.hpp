@@ -57,6 +57,27 @@ public:
         return out;
     }
 
+    // a batch of Welch PSDs (nPsd spans psdStrideBytes apart) spread over several services: spec_welch_psd_multi;
+    // returns nPsd x nfft values, freq (may be null) receives the frequency axis
+    static std::vector<float> welchPsdMulti(const std::vector<const SpectralService *> &services, const void *buffer,
+                                            uint64_t capacity, uint64_t startByte, uint64_t psdStrideBytes, uint32_t nPsd,
+                                            const std::string &datatype, double fs, uint32_t nfft, uint32_t hop,
+                                            uint32_t segments, spec_window window = SPEC_WIN_HANN,
+                                            spec_psd_scaling scaling = SPEC_PSD_DENSITY, bool decibel = false,
+                                            std::vector<double> *freq = nullptr) {
+        if (services.empty()) throw std::invalid_argument("no services");
+        std::vector<spec_ctx *> ctx;
+        for (const SpectralService *s : services) ctx.push_back(s->ctx_);
+        std::vector<float> out((size_t)nPsd * nfft);
+        if (freq) freq->resize(nfft);
+        const void *iq[1] = {buffer};
+        const uint64_t sizes[1] = {capacity};
+        check(spec_welch_psd_multi(ctx.data(), (uint32_t)ctx.size(), iq, 0, sizes, startByte, psdStrideBytes, nPsd,
+                                   spec_dtype_from_sigmf(datatype.c_str()), nfft, hop, segments, window, scaling, fs,
+                                   decibel ? 1 : 0, freq ? freq->data() : nullptr, out.data(), 0), ctx[0]);
+        return out;
+    }
+
     // PowerSpectralDensity.calculatePsdWelch(data, fs, nfft) (AnalysisDialogController.java:308-312):
     // returns {freq, psd}.  psd is in dB/Hz (10 log10(P + 1e-20)) by default: the caller adds a dB offset to it
     // (AnalysisDialogController.java:319-328), labels clicked values "dB" (:612, :626), takes the SNR as their

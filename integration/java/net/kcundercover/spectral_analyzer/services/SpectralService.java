@@ -87,6 +87,27 @@ public class SpectralService implements AutoCloseable {
         return tile;
     }
 
+    /**
+     * A batch of Welch PSDs -- {@code nPsd} spans of the buffer, {@code psdStrideBytes} apart, e.g. one per annotation --
+     * spread over several services, one per GPU: the PSDs are independent, service {@code r} of {@code n} takes the
+     * contiguous range {@code [r nPsd / n, (r + 1) nPsd / n)} on a host thread of its own inside the library.
+     * Returns {@code nPsd * nfft} values, PSD {@code b} at {@code [b * nfft, (b + 1) * nfft)}; {@code freqOut}
+     * (may be null) receives the frequency axis.  {@code services[0]} reports failures.
+     */
+    public static float[] welchPsdMulti(SpectralService[] services, ByteBuffer buffer, long startByte, long psdStrideBytes,
+                                        int nPsd, String datatype, double sampleRate, int nfft, int hop, int segments,
+                                        int window, int scaling, boolean decibel, double[] freqOut) {
+        long[] handles = new long[services.length];
+        for (int i = 0; i < services.length; i++) {
+            handles[i] = services[i].handle;
+        }
+        double[] freq = freqOut != null ? freqOut : new double[nfft];
+        float[] psd = new float[Math.multiplyExact(nPsd, nfft)];
+        nativeWelchMulti(handles, buffer, startByte, psdStrideBytes, nPsd, nativeDtype(datatype), nfft, hop, segments,
+                window, scaling, sampleRate, decibel, freq, psd);
+        return psd;
+    }
+
     /** Welch PSD of the samples from {@code startByte}; returns {frequency axis, psd}. */
     public double[][] welchPsd(ByteBuffer buffer, long startByte, String datatype, double sampleRate,
                                int nfft, int hop, int segments, int window, int scaling, boolean decibel) {
@@ -234,6 +255,9 @@ public class SpectralService implements AutoCloseable {
     private static native void nativeWelch(long handle, ByteBuffer buffer, long startByte, int dtype, int nfft,
                                            int hop, int segments, int window, int scaling, double sampleRate,
                                            boolean decibel, double[] freq, float[] psd);
+    private static native void nativeWelchMulti(long[] handles, ByteBuffer buffer, long startByte, long psdStrideBytes,
+                                                int nPsd, int dtype, int nfft, int hop, int segments, int window,
+                                                int scaling, double sampleRate, boolean decibel, double[] freq, float[] psd);
     private static native void nativeWaterfallRender(long handle, ByteBuffer buffer, long startByte, int dtype,
                                                      int nfft, int hop, int width, int window, int height,
                                                      double sampleRate, double minDb, double maxDb, int colorMap,

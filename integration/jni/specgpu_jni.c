@@ -141,6 +141,38 @@ JNIEXPORT void JNICALL JNI_FN(nativeWelch)(JNIEnv *env, jclass k, jlong h, jobje
     if (st != SPEC_OK) throw_status(env, ctx, st);
 }
 
+/* a batch of PSDs (nPsd spans psdStrideBytes apart) spread over several services: freq[nfft], psd[nPsd * nfft] */
+JNIEXPORT void JNICALL JNI_FN(nativeWelchMulti)(JNIEnv *env, jclass k, jlongArray handles, jobject buffer, jlong startByte,
+                                                 jlong psdStrideBytes, jint nPsd, jint dtype, jint nfft, jint hop, jint nSeg,
+                                                 jint window, jint scaling, jdouble fs, jboolean db, jdoubleArray freq,
+                                                 jfloatArray psd) {
+    (void)k;
+    const jsize n = (*env)->GetArrayLength(env, handles);
+    if (n < 1 || n > 64) { throw_shim(env, "welchPsdMulti: 1 ... 64 services"); return; }
+    void *base = (*env)->GetDirectBufferAddress(env, buffer);
+    jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
+    if (!base || cap < 0) { throw_shim(env, "welchPsdMulti: not a direct buffer"); return; }
+    if (nfft < 0 || nPsd < 0 || startByte < 0 || psdStrideBytes < 0 || (*env)->GetArrayLength(env, freq) < nfft ||
+        (jlong)(*env)->GetArrayLength(env, psd) < (jlong)nPsd * nfft) {
+        throw_shim(env, "welchPsdMulti: freq is shorter than nfft or psd than nPsd * nfft");
+        return;
+    }
+    spec_ctx *ctx[64];
+    jlong *h = (*env)->GetLongArrayElements(env, handles, NULL);
+    for (jsize i = 0; i < n; ++i) ctx[i] = (spec_ctx *)(intptr_t)h[i];
+    (*env)->ReleaseLongArrayElements(env, handles, h, JNI_ABORT);
+    const void *iq[1] = {base};
+    const uint64_t n_bytes[1] = {(uint64_t)cap};
+    jdouble *f = (*env)->GetDoubleArrayElements(env, freq, NULL);
+    jfloat *p = (*env)->GetFloatArrayElements(env, psd, NULL);
+    spec_status st = spec_welch_psd_multi(ctx, (uint32_t)n, iq, 0, n_bytes, (uint64_t)startByte, (uint64_t)psdStrideBytes,
+                                          (uint32_t)nPsd, (spec_dtype)dtype, (uint32_t)nfft, (uint32_t)hop, (uint32_t)nSeg,
+                                          (spec_window)window, (spec_psd_scaling)scaling, fs, db ? 1 : 0, f, p, 0);
+    (*env)->ReleaseFloatArrayElements(env, psd, p, st == SPEC_OK ? 0 : JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, freq, f, st == SPEC_OK ? 0 : JNI_ABORT);
+    if (st != SPEC_OK) throw_status(env, ctx[0], st);
+}
+
 /* one redraw: MainController.updateDisplay() slice loop + renderSpectrogram (MC:962-1049, MC:1261-1291);
  * argb receives height*width IntArgb pixels (B,G,R,A bytes = little-endian int), ready for
  * PixelWriter.setPixels(0, 0, w, h, PixelFormat.getIntArgbInstance(), argb, 0, w) */

@@ -9,10 +9,10 @@ from ._lib import (CMAP_GRAYSCALE, CMAP_HEATMAP, DT_CF32_BE, DT_CF32_LE, DT_CF64
                    DT_CU8, DT_UNKNOWN, OUT_DB20_F32, OUT_DB20_F64, OUT_POW_F32, OUT_POW_F64,
                    PSD_DENSITY, PSD_SPECTRUM, WIN_HANN, WIN_RECT)
 from .spectral_service import (SpectralService, bytes_per_sample, compute_waterfall_multi, dtype_from_sigmf,  # noqa: F401
-                               shard_lines, shard_span)
+                               shard_lines, shard_span, welch_psd_multi)
 
 from .extract_down_convert_service import ExtractDownConvertService  # noqa: F401,E402
 from . import sigmf  # noqa: F401,E402
 
 __all__ = ["SpectralService", "ExtractDownConvertService", "bytes_per_sample", "dtype_from_sigmf", "sigmf",
-           "compute_waterfall_multi", "shard_lines", "shard_span"]
+           "compute_waterfall_multi", "welch_psd_multi", "shard_lines", "shard_span"]

@@ -58,6 +58,8 @@ SIGNATURES = {
     "spec_compute_magnitudes_recording": (_i32, [_vp, _vp, _u64, _u32, _cp, _i32, _vp]),
     "spec_welch_psd": (_i32, [_vp, _vp, _i32, _u64, _u64, _u64, _u32, _i32, _u32, _u32, _u32, _i32, _i32,
                               _dbl, _i32, _vp, _vp, _i32]),
+    "spec_welch_psd_multi": (_i32, [C.POINTER(_vp), _u32, C.POINTER(_vp), _i32, C.POINTER(_u64), _u64, _u64, _u32, _i32, _u32, _u32,
+                                    _u32, _i32, _i32, _dbl, _i32, _vp, _vp, _i32]),
     "spec_render_spectrogram": (_i32, [_vp, _vp, _i32, _u32, _u32, _u32, _dbl, _dbl, _dbl, _i32, _vp, _i32]),
     "spec_waterfall_render": (_i32, [_vp, _vp, _i32, _u64, _u64, _i32, _u32, _u32, _u32, _i32, _u32, _dbl, _dbl,
                                      _dbl, _i32, _vp, _i32]),

@@ -1536,6 +1536,76 @@ spec_status spec_welch_psd(spec_ctx *c, const void *iq, int iq_on_device, uint64
                       fs, db, freq_out, psd_out, out_on_device, false);
 }
 
+// The batch of spec_welch_psd over several contexts (SURVEY 8e at the C ABI, Welch side): the PSDs of a batch are
+// independent, so context r computes the contiguous range spec_shard_lines(n_psd, n_ctx, r) of them -- one host thread per
+// context, no exchange on the data path; a device-resident result is gathered on ctx[0]'s device with hipMemcpyPeerAsync.
+spec_status spec_welch_psd_multi(spec_ctx *const *ctx, uint32_t n_ctx, const void *const *iq, int iq_on_device,
+                                 const uint64_t *n_bytes, uint64_t start_byte, uint64_t psd_stride_bytes, uint32_t n_psd,
+                                 spec_dtype dt, uint32_t nfft, uint32_t hop, uint32_t n_seg, spec_window window,
+                                 spec_psd_scaling scaling, double fs, int db, double *freq_out, float *psd_out, int out_on_device) {
+    if (!ctx || n_ctx == 0 || !ctx[0]) return SPEC_EINVAL;
+    spec_ctx *root = ctx[0];
+    if (n_ctx > 64) return fail(root, SPEC_EINVAL, "spec_welch_psd_multi: %u contexts (at most 64)", n_ctx);
+    for (uint32_t r = 0; r < n_ctx; ++r) {
+        if (!ctx[r]) return fail(root, SPEC_EINVAL, "spec_welch_psd_multi: context %u is NULL", r);
+        for (uint32_t q = 0; q < r; ++q)
+            if (ctx[q] == ctx[r]) return fail(root, SPEC_EINVAL, "spec_welch_psd_multi: context %u appears twice", r);
+    }
+    if (!iq || !n_bytes || !psd_out || (!iq_on_device && !iq[0])) return fail(root, SPEC_EINVAL, "null buffer");
+    if (n_psd == 0 || n_seg == 0) return fail(root, SPEC_EINVAL, "n_seg and n_psd must be >= 1");
+    if (nfft == 0) return fail(root, SPEC_EINVAL, "nfft must be >= 1");
+    if (!(fs > 0)) return fail(root, SPEC_EINVAL, "fs must be positive");
+    std::vector<spec_status> status(n_ctx, SPEC_OK);
+    auto run = [&](uint32_t r) {
+        uint64_t a = 0, b = 0;
+        spec_shard_lines(n_psd, n_ctx, r, &a, &b);
+        if (b <= a) return;
+        spec_ctx *c = ctx[r];
+        const uint32_t np = (uint32_t)(b - a);
+        const size_t bytes = (size_t)np * nfft * sizeof(float);
+        float *dest = psd_out + a * nfft;
+        const bool via_peer = out_on_device && r != 0;  // a peer of a device-resident result computes into a buffer of its own
+        if (via_peer) {
+            Enter g(c);
+            if ((status[r] = grow(c, &c->multi_buf, &c->multi_buf_bytes, bytes)) != SPEC_OK) return;
+            dest = static_cast<float *>(c->multi_buf);
+        }
+        if (iq_on_device) {
+            if (!iq[r]) { status[r] = fail(c, SPEC_EINVAL, "spec_welch_psd_multi: shard %u has PSDs but no buffer", r); return; }
+            status[r] = welch_impl(c, iq[r], 1, n_bytes[r], 0, psd_stride_bytes, np, dt, nfft, hop, n_seg, window, scaling, fs, db,
+                                   nullptr, dest, out_on_device, false);
+        } else {
+            status[r] = welch_impl(c, iq[0], 0, n_bytes[0], start_byte + a * psd_stride_bytes, psd_stride_bytes, np, dt, nfft, hop,
+                                   n_seg, window, scaling, fs, db, nullptr, dest, out_on_device, false);
+        }
+        if (status[r] != SPEC_OK || !out_on_device) return;
+        Enter g(c);
+        hipError_t e = hipSuccess;
+        if (via_peer) e = hipMemcpyPeerAsync(psd_out + a * nfft, root->device, dest, c->device, bytes, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) status[r] = fail(c, SPEC_EDEVICE, "peer copy: %s", hipGetErrorString(e));
+    };
+    std::vector<std::thread> th;
+    for (uint32_t r = 1; r < n_ctx; ++r) {
+        try { th.emplace_back(run, r); }
+        catch (...) { run(r); }  // no thread to be had: this shard runs here
+    }
+    run(0);
+    for (auto &t : th) t.join();
+    for (uint32_t r = 0; r < n_ctx; ++r)
+        if (status[r] != SPEC_OK) {
+            if (r) {
+                std::string msg;
+                { std::lock_guard<std::recursive_mutex> lk(ctx[r]->mu); msg = ctx[r]->err; }
+                return fail(root, status[r], "shard %u of %u: %s", r, n_ctx, msg.c_str());
+            }
+            return status[r];
+        }
+    if (freq_out)  // AnalysisDialogController.java:324-328 adds centerFreq to this axis
+        for (uint32_t k = 0; k < nfft; ++k) freq_out[k] = ((double)k - (double)(nfft / 2)) * fs / (double)nfft;
+    return SPEC_OK;
+}
+
 // Exact shape of the call at AnalysisDialogController.java:308-312:
 //   PowerSpectralDensity.calculatePsdWelch(double[][] data, double fs, int nfft)
 // with data[0] = I, data[1] = Q (planar doubles, the output of the down-converter).

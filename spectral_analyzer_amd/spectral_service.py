@@ -119,6 +119,57 @@ def compute_waterfall_multi(services, buffer, start_byte: int, nfft: int, dataty
     return res
 
 
+def welch_psd_multi(services, buffer, start_byte: int, datatype: str, fs: float, nfft: int, hop: int, n_seg: int,
+                    n_psd: int, psd_stride_bytes: int, window: int = L.WIN_HANN, scaling: int = L.PSD_DENSITY,
+                    db: bool = False, out=None):
+    """``spec_welch_psd_multi``: a batch of PSDs (``SpectralService.welch_psd`` with ``n_psd`` > 1) spread over several
+    contexts -- the PSDs are independent, context r takes ``shard_lines(n_psd, len(services), r)`` of them, one host
+    thread per context inside the library, nothing exchanged on the data path.
+
+    ``buffer``: host bytes (every context stages the span of its own PSDs), or a LIST of CUDA uint8 tensors, entry r
+    on ``services[r]``'s device starting at the first byte of shard r's first PSD (None for a shard without PSDs).
+    ``out``: None / numpy float32 array -> host result; a CUDA float32 tensor on ``services[0]``'s device -> the peers
+    send their rows there.  Returns ``(freq[nfft], psd[n_psd, nfft])`` -- what one context returns (bit for bit while both
+    take the same form of the kernel; include/specgpu.h)."""
+    lib = L.load()
+    dt = dtype_from_sigmf(datatype)
+    n = len(services)
+    ctxs = (C.c_void_p * n)(*[s._ctx for s in services])
+    keep = None
+    if isinstance(buffer, (list, tuple)):
+        import torch
+        if len(buffer) != n:
+            raise ValueError("device input: one tensor (or None) per service")
+        for t in buffer:
+            if t is not None and (not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous()):
+                raise ValueError("device buffers must be contiguous CUDA uint8 tensors")
+        bufs = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None for t in buffer])
+        sizes = (C.c_uint64 * n)(*[int(t.numel()) if t is not None else 0 for t in buffer])
+        on_dev = 1
+    else:
+        keep = _host_bytes(buffer)
+        bufs = (C.c_void_p * n)(*([C.c_void_p(keep.ctypes.data)] + [None] * (n - 1)))
+        sizes = (C.c_uint64 * n)(*([int(keep.size)] + [0] * (n - 1)))
+        on_dev = 0
+    if out is not None and _is_torch(out):
+        import torch
+        if not out.is_cuda or out.dtype != torch.float32 or out.numel() < n_psd * nfft or not out.is_contiguous():
+            raise ValueError("out tensor has the wrong dtype/size")
+        res, out_ptr, out_dev = out, out.data_ptr(), 1
+    else:
+        res = np.empty((int(n_psd), int(nfft)), dtype=np.float32) if out is None else out
+        if not isinstance(res, np.ndarray) or res.dtype != np.float32 or res.size < n_psd * nfft or not res.flags.c_contiguous:
+            raise ValueError("out array has the wrong dtype/size")
+        out_ptr, out_dev = res.ctypes.data, 0
+    freq = np.empty(max(int(nfft), 0), dtype=np.float64)
+    st = lib.spec_welch_psd_multi(ctxs, n, bufs, on_dev, sizes, int(start_byte), int(psd_stride_bytes), int(n_psd), dt,
+                                  int(nfft) & 0xFFFFFFFF, int(hop), int(n_seg), window, scaling, float(fs), int(db),
+                                  freq.ctypes.data, out_ptr, out_dev)
+    del keep
+    services[0]._check(st)
+    return freq, res
+
+
 class SpectralService:
     """GPU-backed drop-in for the reference ``SpectralService`` singleton."""
 

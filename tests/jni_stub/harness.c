@@ -29,6 +29,8 @@ void SS(nativeWaterfall)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, ji
 void SS(nativeWaterfallMulti)(JNIEnv *, jclass, jlongArray, jobject, jlong, jint, jint, jint, jlong, jint, jdouble, jfloatArray);
 void SS(nativeWelch)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, jint, jint, jint, jint, jdouble, jboolean,
                      jdoubleArray, jfloatArray);
+void SS(nativeWelchMulti)(JNIEnv *, jclass, jlongArray, jobject, jlong, jlong, jint, jint, jint, jint, jint, jint, jint, jdouble,
+                          jboolean, jdoubleArray, jfloatArray);
 void SS(nativeWaterfallRender)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, jint, jint, jint, jint, jdouble,
                                jdouble, jdouble, jint, jintArray);
 void SS(nativeWelchPlanar)(JNIEnv *, jclass, jlong, jdoubleArray, jdoubleArray, jint, jint, jint, jint, jdouble,
@@ -205,6 +207,27 @@ int main(void) {
         fake_obj a_twice = mk_array(twice, 2, 8);
         SS(nativeWaterfallMulti)(env, NULL, &a_twice, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile);
         expect_throw("java/lang/IllegalArgumentException", "appears twice", "same service twice");
+        /* a batch of five PSDs over the same three services: what one context returns for the batch */
+        {
+            enum { NPSD = 5, SEG = 6, WH = 512 };
+            const jlong stride = 4 * 9000;
+            static float psd[NPSD * NFFT], psd_ref[NPSD * NFFT];
+            double fq[NFFT], fq_ref[NFFT];
+            fake_obj a_psd = mk_array(psd, NPSD * NFFT, 4), a_fq = mk_array(fq, NFFT, 8);
+            SS(nativeWelchMulti)(env, NULL, &a_hs, &buf, 400, stride, NPSD, SPEC_DT_CI16_LE, NFFT, WH, SEG, SPEC_WIN_HANN,
+                                 SPEC_PSD_DENSITY, 2.0e6, 1, &a_fq, &a_psd);
+            expect_clean("welchPsdMulti");
+            CHECK(spec_welch_psd(ref, rec, 0, SAMPLES * 4, 400, (uint64_t)stride, NPSD, SPEC_DT_CI16_LE, NFFT, WH, SEG, SPEC_WIN_HANN,
+                                 SPEC_PSD_DENSITY, 2.0e6, 1, fq_ref, psd_ref, 0) == SPEC_OK, "abi");
+            CHECK(memcmp(psd, psd_ref, sizeof psd) == 0 && memcmp(fq, fq_ref, sizeof fq) == 0, "welchPsdMulti differs from the single-context batch");
+            fake_obj a_psd_short = mk_array(psd, NPSD * NFFT - 1, 4);
+            SS(nativeWelchMulti)(env, NULL, &a_hs, &buf, 400, stride, NPSD, SPEC_DT_CI16_LE, NFFT, WH, SEG, SPEC_WIN_HANN,
+                                 SPEC_PSD_DENSITY, 2.0e6, 1, &a_fq, &a_psd_short);
+            expect_throw("java/lang/IllegalArgumentException", "shorter than", "short psd array (multi)");
+            SS(nativeWelchMulti)(env, NULL, &a_hs, &buf, 400, stride, NPSD, SPEC_DT_CI16_LE, NFFT, WH, 4000, SPEC_WIN_HANN,
+                                 SPEC_PSD_DENSITY, 2.0e6, 1, &a_fq, &a_psd);
+            expect_throw("java/lang/IndexOutOfBoundsException", "needs bytes", "segments past the end (multi)");
+        }
         SS(nativeDestroy)(env, NULL, hs[1]);
         SS(nativeDestroy)(env, NULL, hs[2]);
     }

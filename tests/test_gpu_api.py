@@ -721,3 +721,54 @@ def test_last_error_is_not_inherited_from_a_destroyed_context(oracle):
             assert b._lib.spec_last_error(b._ctx) == b"", (hex(addr), hex(b._ctx.value))
         finally:
             b.close()
+
+
+@pytest.mark.parametrize("datatype,nfft,hop,n_seg,n_psd", [("cf32_le", 1024, 512, 6, 7), ("ci16_le", 4096, 1024, 9, 600),
+                                                           ("cf64_le", 2048, 2048, 3, 5), ("cu8", 1000, 300, 4, 2),
+                                                           ("cf32_le", 256, 64, 33, 1)])
+def test_welch_multi_equals_the_single_context_batch(svc, oracle, datatype, nfft, hop, n_seg, n_psd):
+    """spec_welch_psd_multi: the PSDs of a batch sharded over three contexts (all on device 0 on the one-GPU box) -- host
+    buffer -> host result, and device-resident shards -> a result on the consumer's device (the peers' rows sent with
+    hipMemcpyPeerAsync) -- are what one context returns for the batch: bit for bit while both take the same form of the kernel,
+    to the rounding of the fp32 segment sums otherwise (a batch of >= two PSDs per CU is summed in one pass by the workgroup
+    that walks the PSD, smaller ones in runs of <= 64 segments: 600 PSDs in one context against 200 in each of three); a
+    shard may be empty (fewer PSDs than contexts); linear and dB."""
+    import torch
+    bps = oracle.bytes_per_sample(datatype)
+    per = (n_seg - 1) * hop + nfft + 5
+    start = 3
+    if n_psd > 50:
+        iq = svc.synth_iq(datatype, 31, 0, start + per * n_psd).cpu().numpy()
+    else:
+        iq = oracle.synth_iq(datatype, 31, 0, start + per * n_psd)
+    fs = 3.0e6
+    peers = [sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream) for _ in range(2)]
+    services = [svc] + peers
+
+    def same(got, one, db):
+        if n_psd <= 50:
+            return np.array_equal(got, one)
+        if db:
+            return np.abs(got - one).max() <= 1e-4
+        return np.abs(got - one).max() <= 2e-6 * one.max()
+
+    try:
+        for db in (False, True):
+            f1, one = svc.welch_psd(iq, start * bps, datatype, fs, nfft=nfft, hop=hop, n_seg=n_seg, n_psd=n_psd, psd_stride_bytes=per * bps, db=db)
+            f, host = sa.welch_psd_multi(services, iq, start * bps, datatype, fs, nfft, hop, n_seg, n_psd, per * bps, db=db)
+            assert np.array_equal(f, f1) and host.dtype == one.dtype and same(host, one, db)
+            shards = []
+            for r in range(3):
+                a, b = sa.shard_lines(n_psd, 3, r)
+                lo, hi = (start + a * per) * bps, (start + (b - 1) * per + (n_seg - 1) * hop + nfft) * bps
+                shards.append(torch.from_numpy(iq[lo:hi].copy()).cuda() if b > a else None)
+            out = torch.full((n_psd, nfft), float("nan"), dtype=torch.float32, device="cuda")
+            _, got = sa.welch_psd_multi(services, shards, 0, datatype, fs, nfft, hop, n_seg, n_psd, per * bps, db=db, out=out)
+            assert got is out and same(out.cpu().numpy(), one, db)
+        with pytest.raises(ValueError):                                     # the same context twice
+            sa.welch_psd_multi([svc, svc], iq, 0, datatype, fs, nfft, hop, n_seg, n_psd, per * bps)
+        with pytest.raises(IndexError):                                     # spec_welch_psd's range error, from a shard
+            sa.welch_psd_multi(services, iq, 0, datatype, fs, nfft, hop, n_seg * 1000, n_psd, per * bps)
+    finally:
+        for p in peers:
+            p.close()

@@ -215,6 +215,18 @@ def test_random_sharded_requests_equal_the_single_context_tile(svc, oracle, seed
                                            out=out, n_chunks=int(rng.integers(0, 7)))
                 got = out.cpu().numpy()
             assert got.dtype == one.dtype and np.array_equal(got, one), tag
+            # a batch of PSDs over the same contexts (spec_welch_psd_multi): small batches take the same form of the kernel in
+            # every context, so the single-context batch comes back bit for bit
+            n_psd, n_seg = int(rng.integers(1, 9)), int(rng.integers(1, 6))
+            wn = 1 << int(rng.choice([4, 8, 10, 12]))
+            whop = int(rng.choice([wn, wn // 2, int(rng.integers(1, wn + 1))]))
+            per = (n_seg - 1) * whop + wn + int(rng.integers(0, 9))
+            wiq = oracle.synth_iq(dt, int(rng.integers(1, 1 << 30)), 0, start + per * n_psd)
+            db = bool(rng.integers(0, 2))
+            f1, p1 = svc.welch_psd(wiq, start * bps, dt, 1e6, nfft=wn, hop=whop, n_seg=n_seg, window=window, n_psd=n_psd,
+                                   psd_stride_bytes=per * bps, db=db)
+            f2, p2 = sa.welch_psd_multi(services, wiq, start * bps, dt, 1e6, wn, whop, n_seg, n_psd, per * bps, window=window, db=db)
+            assert np.array_equal(f1, f2) and np.array_equal(p1, p2), tag + (n_psd, n_seg, wn, whop, db)
     finally:
         for p in peers:
             p.close()
