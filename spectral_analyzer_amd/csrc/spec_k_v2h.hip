@@ -1,0 +1,321 @@
+// spec_k_v2h.hip -- 32768-point fp32 lines in ONE workgroup (round 4).  The top of the reference's NFFT slider
+// (main-scene.fxml:129-132: 2^6 ... 2^16) around SpectralService.java:33-85.
+//
+// A 32768-point cf32 line is 256 KiB: it does not fit the LDS (160 KiB), and until round 3 it went through the
+// four-step team kernel (spec_k_team.hip: sixteen + sixteen workgroups per line, the intermediate handed over in L2,
+// 0.26 of the HBM roofline -- bound by the hand-off chain).  It does fit ONE workgroup's registers and
+// LDS if the first radix-2 step is taken in registers on the way in (decimation in frequency):
+//     a[n] = x[n] + x[n + H],   b[n] = (x[n] - x[n + H]) W_N^n,   H = N/2 = 16384,  n < H
+//     X[2k] = FFT_H(a)[k],      X[2k + 1] = FFT_H(b)[k]
+// and the two 16384-point transforms run one after the other through the SAME LDS buffer with the family's own
+// passes (Plan2<14>: 512 threads, 32 points each, radix 32 x 32 x 16, two exchanges).  No other workgroup is waited
+// for, nothing but the line's samples and bins crosses the CU's boundary.
+//   * thread t owns n = t + 512 m (m < 32) of both halves, so W_N^n = W_N^t W_64^m: one per-thread twiddle and 32
+//     compile-time constants;
+//   * the even bins wait as 32 finished floats per thread while the odd half is transformed, then leave in PAIRS
+//     (X[2k], X[2k+1]: 8-byte stores, 512 bytes per wave and instruction), fftshift (SS:78) folded into the index;
+//   * register budget (256 at two waves per SIMD): transform state 64 + 64, plus what is parked.  cf32: the difference
+//     d = lo - hi (64 registers) during the first transform; the next line's lower half is requested at the start of the
+//     first transform, the upper half in two pieces around the second -- no room to keep the 50 %-overlap half in
+//     registers, it comes back from L2 / the Infinity Cache.  2- and 4-byte formats: the raw samples themselves are
+//     parked (32 + 32 registers, decoded twice) and at hop = N/2 the upper half STAYS as the next line's lower half.
+#include "spec_v2.h"
+
+namespace specgpu {
+
+namespace {
+
+struct V2hArgs {
+    const uint8_t *iq;     // first byte of line 0
+    uint32_t n_lines, hop, run;  // run: consecutive lines per workgroup
+    const void *tw_half;   // v2f W_16384^m
+    const void *tw_full;   // v2f W_32768^m
+    const void *win;       // float[32768] or nullptr
+    float *out;
+    int out_fmt;
+};
+
+// W_64^m = exp(-2 pi i m / 64), m = 0 .. 31
+__device__ static constexpr double kW64[32][2] = {
+    {1.0, 0.0},
+    {0.995184726672196886245, -0.0980171403295606019942},
+    {0.980785280403230449126, -0.195090322016128267848},
+    {0.956940335732208864936, -0.290284677254462367636},
+    {0.923879532511286756128, -0.382683432365089771728},
+    {0.881921264348355029713, -0.471396736825997648556},
+    {0.831469612302545237079, -0.555570233019602224743},
+    {0.773010453362736960811, -0.634393284163645498215},
+    {0.707106781186547524401, -0.707106781186547524401},
+    {0.634393284163645498215, -0.773010453362736960811},
+    {0.555570233019602224743, -0.831469612302545237079},
+    {0.471396736825997648556, -0.881921264348355029713},
+    {0.382683432365089771728, -0.923879532511286756128},
+    {0.290284677254462367636, -0.956940335732208864936},
+    {0.195090322016128267848, -0.980785280403230449126},
+    {0.0980171403295606019942, -0.995184726672196886245},
+    {0.0, -1.0},
+    {-0.0980171403295606019942, -0.995184726672196886245},
+    {-0.195090322016128267848, -0.980785280403230449126},
+    {-0.290284677254462367636, -0.956940335732208864936},
+    {-0.382683432365089771728, -0.923879532511286756128},
+    {-0.471396736825997648556, -0.881921264348355029713},
+    {-0.555570233019602224743, -0.831469612302545237079},
+    {-0.634393284163645498215, -0.773010453362736960811},
+    {-0.707106781186547524401, -0.707106781186547524401},
+    {-0.773010453362736960811, -0.634393284163645498215},
+    {-0.831469612302545237079, -0.555570233019602224743},
+    {-0.881921264348355029713, -0.471396736825997648556},
+    {-0.923879532511286756128, -0.382683432365089771728},
+    {-0.956940335732208864936, -0.290284677254462367636},
+    {-0.980785280403230449126, -0.195090322016128267848},
+    {-0.995184726672196886245, -0.0980171403295606019942}};
+
+// d * W_64^M * wt
+template <int M> __device__ __forceinline__ v2f v2h_twiddle(v2f d, v2f wt) {
+    if constexpr (M == 0) return pk_cmul(d, wt);
+    else if constexpr (M == 16) return pk_cmul(pk_mul_mi(d), wt);
+    else return pk_cmul(pk_cmul_const(d, kW64[M][0], kW64[M][1]), wt);
+}
+template <typename F, int... M> __device__ __forceinline__ void v2h_for_each(F &&f, std::integer_sequence<int, M...>) {
+    (f(std::integral_constant<int, M>{}), ...);
+}
+
+// ---- epilogue: 20 log10(|X| + 1e-10) (SS:80-81), one range test per thread as in the family (spec_v2.h v2_epilogue) ----
+// The family inlines the exact form db20() -- three branches -- once per bin behind the range test.  In this kernel the
+// allocator then keeps the spectrum alive through all 32 of them and the HOT path loses 40 registers, exactly the room
+// the next line's samples need.  Here the forms behind the fast one are straight-line code (selects, no branches):
+//   * from |X|^2 alone while nothing can overflow (every integer format; cf32 with every |X|^2 < 1e37):
+//       p > 1e-4 ? 10 log10(p) : 20 log10(sqrt(p) + 1e-10)            (|X| + 1e-10 == |X| in fp32 above that)
+//   * cf32 with a huge, infinite or NaN value somewhere in the thread's bins: additionally the rescaled form
+//       10 log10((x 2^-64)^2 + (y 2^-64)^2) + 10 log10(2^128)          for p >= 1e37
+// The values are db20()'s (spec_fft.h) bin for bin.
+template <bool BOUNDED, int E> __device__ __forceinline__ void v2h_epilogue(const v2f (&v)[E], float scale, bool db, float (&d)[E]) {
+    float p[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) p[m] = pk_norm(v[m]);
+    const float s2 = scale * scale;  // a power of two for the integer formats, 1 for cf32: p s2 is exact
+    if (!db) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) d[m] = p[m] * s2;
+        return;
+    }
+    float lo = fminf(fminf(p[0], p[1]), p[2]), hi = 0.0f;
+#pragma unroll
+    for (int m = 3; m + 1 < E; m += 2) lo = fminf(fminf(lo, p[m]), p[m + 1]);
+    lo = fminf(lo, p[E - 1]);
+    if constexpr (!BOUNDED) {
+        hi = fmaxf(fmaxf(p[0], p[1]), p[2]);
+#pragma unroll
+        for (int m = 3; m + 1 < E; m += 2) hi = fmaxf(fmaxf(hi, p[m]), p[m + 1]);
+        hi = fmaxf(hi, p[E - 1]);
+    }
+    constexpr float k10 = 3.01029995663981195f;  // 10 log10(2)
+    const float off = k10 * __log2f(s2);
+    if (lo * s2 > 1e-4f && hi < 1e37f) {  // a NaN fails the first test
+#pragma unroll
+        for (int m = 0; m < E; m += 2) {  // two bins per v_pk_fma_f32
+            const v2f r = __builtin_elementwise_fma(v2f{__log2f(p[m]), __log2f(p[m + 1])}, v2f{k10, k10}, v2f{off, off});
+            d[m] = r.x;
+            d[m + 1] = r.y;
+        }
+        return;
+    }
+    bool from_p = true;
+    if constexpr (!BOUNDED) from_p = hi < 1e37f;  // (fmaxf drops NaNs: a NaN bin is carried by the select below)
+    if (from_p) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const float ps = p[m] * s2;
+            d[m] = ps > 1e-4f ? k10 * __log2f(ps) : 2.0f * k10 * __log2f(sqrtf(ps) + 1e-10f);
+        }
+    } else {
+        if constexpr (!BOUNDED) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const float ps = p[m];
+                const float xs = v[m].x * (1.0f / 1.8446744e19f), ys = v[m].y * (1.0f / 1.8446744e19f);  // 2^-64
+                const float r3 = k10 * (__log2f(__builtin_fmaf(xs, xs, ys * ys)) + 128.0f);
+                const float r12 = ps > 1e-4f ? k10 * __log2f(ps) : 2.0f * k10 * __log2f(sqrtf(ps) + 1e-10f);
+                d[m] = ps >= 1e37f ? r3 : r12;
+            }
+        }
+    }
+}
+
+#ifndef V2H_PF
+#define V2H_PF 16  // cf32: samples of the next line's lower half requested at the start of the second transform
+#endif
+
+// REUSE: hop == N/2 and a 2- / 4-byte format -- the raw upper half stays in registers as the next line's lower half
+template <int KIND, bool HAS_WIN, bool BE, bool REUSE>
+__global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
+    constexpr int L = 14;
+    using PL = Plan2<L>;
+    using RW = Raw2<KIND>;
+    using raw_t = typename RW::type;
+    constexpr int BPS = RW::BPS, H = PL::N, N = 2 * H, T = PL::T, E = PL::E;
+    constexpr bool PARK_RAW = KIND != K_CF32;  // park the raw samples (E + E registers) instead of the decoded difference
+    constexpr int PF = V2H_PF;
+    static_assert(!REUSE || PARK_RAW, "register reuse needs the raw halves parked");
+    static_assert(T == 512 && E == 32, "one 512-thread workgroup, 32 points per thread and half");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    v2f *lds = reinterpret_cast<v2f *>(smem);
+    v2f *tab = reinterpret_cast<v2f *>(smem + (size_t)PL::LINE * 8);
+    const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw_half);
+
+    fill_tables<L, 1>(tab, tw, t);
+    v2f twl[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (H - 1)];
+    const v2f wt = static_cast<const v2f *>(a.tw_full)[t];  // W_N^t
+    const float *win = static_cast<const float *>(a.win);
+    const bool db = a.out_fmt == OUT_DB20_F32;
+
+    const uint32_t line0 = blockIdx.x * a.run;
+    uint32_t lines_wg = a.n_lines - line0;
+    if (lines_wg > a.run) lines_wg = a.run;
+    const uint32_t line_bytes = a.hop * BPS;
+    // (lw: the same number behind an empty asm.  Left visible, hipcc merges "lines_wg - 1" with the loop guard
+    // "lines_wg == 0" into ONE v_sub_co_u32 -- a VALU instruction -- the descriptor's size becomes a vector register and
+    // every buffer access of the kernel a readfirstlane loop.)
+    uint32_t lw = lines_wg;
+    asm volatile("" : "+s"(lw));
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(a.iq) + (uint64_t)line0 * line_bytes, 0, (lw - 1) * line_bytes + (uint32_t)N * BPS, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(a.out + (uint64_t)line0 * N, 0, lw * (uint32_t)N * 4u, 0x00020000);
+    const int voff = t * BPS, ovoff = t * 8;
+    constexpr int AUX = 2, ST_AUX = 2;  // non-temporal, as the family
+    // cf32 without register reuse: the overlapped half is read a second time one line later -- cached (L2 / MALL) on
+    // its first reading, non-temporal on its last
+    constexpr int AUX_HI = PARK_RAW ? 2 : 0;
+
+    raw_t rlo[E], rhi[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) rlo[m] = RW::template load<AUX>(src, voff, m * T * BPS);
+#pragma unroll
+    for (int m = 0; m < E; ++m) rhi[m] = RW::template load<AUX_HI>(src, voff, (m + E) * T * BPS);
+
+    __syncthreads();  // LDS twiddle table visible
+
+    for (uint32_t line = 0; line < lines_wg; ++line) {
+        const int next_off = (int)((line + 1) * line_bytes);
+        v2f v[E], dd[PARK_RAW ? 1 : E];
+        (void)dd;
+        const float *wp = win;
+        if constexpr (HAS_WIN) asm volatile("" : "+s"(wp));  // keep the window loads inside the loop
+        auto decode = [&](int m, v2f &lo, v2f &hi) {
+            lo = RW::dec(BE ? RW::swap(rlo[m]) : rlo[m]);  // SMH:87-91 byte order
+            hi = RW::dec(BE ? RW::swap(rhi[m]) : rhi[m]);
+            if constexpr (HAS_WIN) {
+                const float w0 = wp[t + m * T], w1 = wp[H + t + m * T];
+                lo *= v2f{w0, w0};
+                hi *= v2f{w1, w1};
+            }
+        };
+        // ---- first radix-2 step, even half: a = lo + hi ----
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            v2f lo, hi;
+            decode(m, lo, hi);
+            v[m] = lo + hi;
+            if constexpr (!PARK_RAW) {
+                dd[m] = lo - hi;
+                // computed HERE: left alone, hipcc sinks the subtraction to its use behind the first transform and keeps
+                // lo and hi -- 128 registers instead of 64 -- alive across it
+                asm volatile("" : "+v"(dd[m]));
+            }
+        }
+        v2_fft<L>(v, t, lds, tab, twl);
+        float de[E];
+        constexpr bool BOUNDED = KIND != K_CF32;
+        v2h_epilogue<BOUNDED, E>(v, RW::SCALE, db, de);
+
+        // ---- odd half: b = (lo - hi) W_N^(t + 512 m) = d W_64^m W_N^t ----
+        v2h_for_each([&](auto mt) {
+            constexpr int m = decltype(mt)::value;
+            if constexpr (PARK_RAW) {
+                v2f lo, hi;
+                // decoded a second time from the parked raw registers; the empty asm keeps hipcc from re-using the first
+                // decode's floats instead (128 registers alive across the first transform)
+                asm volatile("" : "+v"(rlo[m]), "+v"(rhi[m]));
+                if constexpr (HAS_WIN && m == 0) asm volatile("" : "+s"(wp));  // ... nor its 64 window values
+                decode(m, lo, hi);
+                v[m] = v2h_twiddle<m>(lo - hi, wt);
+            } else {
+                v[m] = v2h_twiddle<m>(dd[m], wt);
+            }
+        }, std::make_integer_sequence<int, E>{});
+        if constexpr (PARK_RAW) {  // the whole next line is requested here and lands behind the second transform
+            if constexpr (REUSE) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) rlo[m] = rhi[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < E; ++m) rlo[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
+            }
+#pragma unroll
+            for (int m = 0; m < E; ++m) rhi[m] = RW::template load<AUX_HI>(src, voff, next_off + (m + E) * T * BPS);
+        } else {  // cf32: PF samples of the next line's lower half fit beside the second transform
+#pragma unroll
+            for (int m = 0; m < PF; ++m) rlo[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
+        }
+        v2_fft<L>(v, t, lds, tab, twl);
+        float dq[E];
+        v2h_epilogue<BOUNDED, E>(v, RW::SCALE, db, dq);
+        if constexpr (!PARK_RAW) {  // (the spectrum's registers are free again) the rest of the next line
+#pragma unroll
+            for (int m = PF; m < E; ++m) rlo[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
+#pragma unroll
+            for (int m = 0; m < E; ++m) rhi[m] = RW::template load<AUX_HI>(src, voff, next_off + (m + E) * T * BPS);
+        }
+        // ---- bins 2k, 2k + 1 (k = t + 512 m) at columns 2c, 2c + 1, c = (k + H/2) mod H   (SS:78) ----
+        const int out_off = (int)(line * (uint32_t)N * 4u);
+#pragma unroll
+        for (int m = 0; m < E; ++m)
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(de[m]), __float_as_uint(dq[m])}, dst, ovoff,
+                                                  out_off + ((m + E / 2) & (E - 1)) * T * 8, ST_AUX);
+    }
+}
+
+template <int KIND, bool HAS_WIN, bool BE, bool REUSE> hipError_t v2h_launch1(const V2hArgs &a, hipStream_t s) {
+    constexpr size_t lds = p2_lds_bytes<14>();
+    auto kern = v2h_kernel<KIND, HAS_WIN, BE, REUSE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((a.n_lines + a.run - 1) / a.run), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int KIND, bool BE> hipError_t v2h_launch_kind(const V2hArgs &a, hipStream_t s) {
+    const bool win = a.win != nullptr;
+    if constexpr (KIND != K_CF32) {
+        if (a.hop == 16384u) return win ? v2h_launch1<KIND, true, BE, true>(a, s) : v2h_launch1<KIND, false, BE, true>(a, s);
+    }
+    return win ? v2h_launch1<KIND, true, BE, false>(a, s) : v2h_launch1<KIND, false, BE, false>(a, s);
+}
+
+}  // namespace
+
+bool v2h_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop) {
+    if (log2n != 15) return false;
+    if (kind != K_CF32 && kind != K_CI16 && kind != K_CU8 && kind != K_CI8) return false;
+    if (out_fmt != OUT_DB20_F32 && out_fmt != OUT_POW_F32) return false;
+    return n_lines > 0 && n_lines < (1ull << 31) && hop <= (8u << 15);  // a workgroup's span stays far below 4 GiB
+}
+
+hipError_t launch_v2h_spectro(const WfArgs &w, const void *tw_half, uint32_t run, hipStream_t s) {
+    V2hArgs a{};
+    a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.run = run;
+    a.tw_half = tw_half; a.tw_full = w.tw; a.win = w.win;
+    a.out = static_cast<float *>(w.out); a.out_fmt = w.out_fmt;
+    switch (w.kind) {
+    case K_CF32: return w.be ? v2h_launch_kind<K_CF32, true>(a, s) : v2h_launch_kind<K_CF32, false>(a, s);
+    case K_CI16: return w.be ? v2h_launch_kind<K_CI16, true>(a, s) : v2h_launch_kind<K_CI16, false>(a, s);
+    case K_CU8: return v2h_launch_kind<K_CU8, false>(a, s);
+    case K_CI8: return v2h_launch_kind<K_CI8, false>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace specgpu

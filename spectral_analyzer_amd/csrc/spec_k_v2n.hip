@@ -106,20 +106,30 @@ __global__ __launch_bounds__(256, V2N_OCC) void v2n_kernel(const V2nArgs a) {
         // ---- this lane's 16 samples: x[j hop + t + m T] ----
         v2f v[E];
         const uint32_t base = mis + (uint32_t)j * line_bytes + (uint32_t)t * BPS;
+        // SPLIT (cf32 only): the recording starts at 4 mod 8 bytes (include/specgpu.h promises component alignment only),
+        // so a sample's two words may lie on either side of a pad gap: each word gets its own padded address.  `mis & 4`
+        // is the same for every lane and block of the call (line strides and lane offsets are multiples of 8).
+        auto pick = [&](auto split_tag) {
+            constexpr bool SPLIT = decltype(split_tag)::value;
 #pragma unroll
-        for (int m = 0; m < E; ++m) {
-            const unsigned char *p = region + padded(base + (uint32_t)(m * T * BPS));
-            typename RW::type r;
-            if constexpr (BPS == 8) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(p);  // 4-byte aligned (checked by the host)
-                r = typename RW::type{q[0], q[1]};
-            } else if constexpr (BPS == 4) {
-                r = *reinterpret_cast<const uint32_t *>(p);
-            } else {
-                r = *reinterpret_cast<const uint16_t *>(p);
+            for (int m = 0; m < E; ++m) {
+                const uint32_t x = base + (uint32_t)(m * T * BPS);
+                const unsigned char *p = region + padded(x);
+                typename RW::type r;
+                if constexpr (BPS == 8) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(p);  // 4-byte aligned (checked by the host)
+                    if constexpr (SPLIT) r = typename RW::type{q[0], *reinterpret_cast<const uint32_t *>(region + padded(x + 4u))};
+                    else r = typename RW::type{q[0], q[1]};
+                } else if constexpr (BPS == 4) {
+                    r = *reinterpret_cast<const uint32_t *>(p);
+                } else {
+                    r = *reinterpret_cast<const uint16_t *>(p);
+                }
+                v[m] = RW::dec(BE ? RW::swap(r) : r);  // SMH:87-91 byte order
             }
-            v[m] = RW::dec(BE ? RW::swap(r) : r);  // SMH:87-91 byte order
-        }
+        };
+        if (BPS == 8 && (mis & 4u)) pick(std::true_type{});
+        else pick(std::false_type{});
         if (win) {
 #pragma unroll
             for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};

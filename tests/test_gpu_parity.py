@@ -281,3 +281,25 @@ def test_short_lines_every_hop_and_tail(svc, oracle, nfft, datatype, window):
     finally:
         svc.set_option("force_generic", 0)
     check_fp32(g, oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window), nfft)
+
+
+@pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be"])
+@pytest.mark.parametrize("nfft", [64, 128])
+def test_short_lines_start_at_4_mod_8(svc, oracle, nfft, datatype):
+    """include/specgpu.h promises component alignment only: a cf32 recording may start 4 bytes into an 8-byte word (a
+    4-byte header, a Welch stride of 4 mod 8).  In the 64- / 128-point kernel a sample's two words can then lie on either
+    side of a pad gap of the wave's LDS span (round-3 advisor: mis = 4, hop = 32, N = 64, line 0, t = 3, m = 7): every
+    hop of the family, device buffer at 4 mod 8, against the oracle on the same bytes."""
+    import torch
+    for hop, n_lines in ((nfft // 2, 200), (32, 64), (3, 70), (nfft, 33), (nfft - 7, 19)):
+        n = (n_lines - 1) * hop + nfft
+        body = oracle.synth_iq(datatype, seed=nfft + hop + 4, first_sample=11, n_samples=n)
+        iq = np.concatenate([np.frombuffer(b"\x7f\x80\x01\xfe", np.uint8), body.view(np.uint8)])  # 4 bytes of header
+        ref = oracle.waterfall(iq, 4, datatype, nfft, hop, n_lines)
+        d = torch.from_numpy(iq).cuda()
+        assert d.data_ptr() % 8 == 0
+        got = svc.compute_waterfall(d, 4, nfft, datatype, n_lines, hop=hop)
+        torch.cuda.synchronize()
+        check_fp32(got.cpu().numpy(), ref, nfft)
+        got_h = svc.compute_waterfall(iq, 4, nfft, datatype, n_lines, hop=hop)   # host buffer: staged copy keeps the phase
+        check_fp32(got_h, ref, nfft)
