@@ -53,6 +53,7 @@ WORKLOADS = {
     "n8192": dict(kind="spectro", datatype="cf32_le", nfft=8192, hop=4096, log2s=30, window=0, out="f32"),
     "n16384": dict(kind="spectro", datatype="cf32_le", nfft=16384, hop=8192, log2s=30, window=0, out="f32"),
     "n65536f": dict(kind="spectro", datatype="cf32_le", nfft=65536, hop=32768, log2s=30, window=0, out="f32"),
+    "n32768f": dict(kind="spectro", datatype="cf32_le", nfft=32768, hop=16384, log2s=30, window=0, out="f32"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 GATHER_TIMEOUT_S = 240  # N > 1: the compute + gather phase is abandoned after this long (the headline is kept)
@@ -227,39 +228,54 @@ def main() -> None:
     # ---- outside the timed region: spot check against the oracle, CPU baseline ----
     checked = None
     cpu_baseline = None
+    # EVERY rank checks lines of its OWN shard against the oracle (rank 0's lines say nothing about the other devices);
+    # the verdicts are reduced below.  Rank 0 builds the checker first, the others load the finished library.
     if rank == 0:
         from oracle import spec_oracle as so
         so.build()
-        if welch:
-            pick = sorted(set(int(x) for x in np.linspace(0, n_psd - 1, 3)))
-            worst = 0.0
-            for p in pick:
-                raw = iq[p * per_psd * bps:(p + 1) * per_psd * bps].cpu().numpy()
-                _, ref = so.welch_psd(raw, 0, datatype, nfft, hop, n_seg, window, so.PSD_DENSITY, fs)
-                worst = max(worst, float(np.abs(out[p].cpu().numpy() - ref).max() / ref.max()))
-            checked = {"psds": len(pick), "max_err_over_peak": worst, "tol": 5e-6, "ok": bool(worst <= 5e-6)}
-        else:
-            pick = sorted(set(int(x) for x in np.linspace(0, n_lines - 1, 6)))
-            worst = 0.0
-            for ln in pick:
-                raw = iq[ln * hop * bps:(ln * hop + nfft) * bps].cpu().numpy()
-                ref = so.waterfall(raw, 0, datatype, nfft, hop, 1, window)[0]
-                got = out[ln].cpu().numpy().astype(np.float64)
-                m_ref, m_got = 10 ** (ref / 20), 10 ** (got / 20)
-                worst = max(worst, float(np.abs(m_got - m_ref).max() / (m_ref.max() * np.log2(nfft))))
-            # fp64: against the reference's own transform (commons-math3: twiddles by recurrence, off by up to 4e-17 N M
-            # itself) -- the N-dependent statement of tests/test_gpu_parity.py fp64_tol
-            tol = (max(8e-15 * np.log2(nfft) + 5e-14, 4e-17 * nfft) / np.log2(nfft)) if w["out"] == "f64" else 4e-6
-            checked = {"lines": len(pick), "max_lin_err_over_M_log2N": worst, "tol": tol, "ok": bool(worst <= tol)}
+    if dist is not None:
+        dist.barrier()
+    from oracle import spec_oracle as so
+    so.build()
+    if welch:
+        pick = sorted(set(int(x) for x in np.linspace(0, n_psd - 1, 3)))
+        worst = 0.0
+        for p in pick:
+            raw = iq[p * per_psd * bps:(p + 1) * per_psd * bps].cpu().numpy()
+            _, ref = so.welch_psd(raw, 0, datatype, nfft, hop, n_seg, window, so.PSD_DENSITY, fs)
+            worst = max(worst, float(np.abs(out[p].cpu().numpy() - ref).max() / ref.max()))
+        checked = {"psds": len(pick), "max_err_over_peak": worst, "tol": 5e-6, "ok": bool(worst <= 5e-6)}
+    else:
+        pick = sorted(set(int(x) for x in np.linspace(0, n_lines - 1, 6)))
+        worst = 0.0
+        for ln in pick:
+            raw = iq[ln * hop * bps:(ln * hop + nfft) * bps].cpu().numpy()
+            ref = so.waterfall(raw, 0, datatype, nfft, hop, 1, window)[0]
+            got = out[ln].cpu().numpy().astype(np.float64)
+            m_ref, m_got = 10 ** (ref / 20), 10 ** (got / 20)
+            worst = max(worst, float(np.abs(m_got - m_ref).max() / (m_ref.max() * np.log2(nfft))))
+        # fp64: against the reference's own transform (commons-math3: twiddles by recurrence, off by up to 4e-17 N M
+        # itself) -- the N-dependent statement of tests/test_gpu_parity.py fp64_tol
+        tol = (max(8e-15 * np.log2(nfft) + 5e-14, 4e-17 * nfft) / np.log2(nfft)) if w["out"] == "f64" else 4e-6
+        checked = {"lines": len(pick), "max_lin_err_over_M_log2N": worst, "tol": tol, "ok": bool(worst <= tol)}
+    if dist is not None:
+        # ok_all_ranks: the MINIMUM of the per-rank verdicts; worst_all_ranks: the MAXIMUM of the per-rank errors
+        t = torch.tensor([1.0 if checked["ok"] else 0.0, -worst], dtype=torch.float64, device=red_dev or iq.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        checked["ok_all_ranks"] = bool(t[0].item() >= 1.0)
+        checked["worst_all_ranks"] = float(-t[1].item())
+        checked["ranks_checked"] = world
+    else:
+        checked["ok_all_ranks"] = checked["ok"]
 
-        if world == 1 and not args.no_cpu_baseline:
-            # bounded samples: roughly 1e9 butterfly-points for the all-core run, 1.5e8 for the single thread
-            per_line = nfft * np.log2(nfft)
-            la = int(max(8, min(n_lines, 1.6e9 / per_line)))
-            l1t = int(max(4, min(n_lines, 2.0e8 / per_line)))
-            host = iq[:((la - 1) * hop + nfft) * bps].cpu().numpy()
-            cpu_baseline = cpu_baseline_for(so, host, datatype, nfft, hop, window, la, l1t,
-                                            "segments (Hann, hop %d)" % hop if welch else "lines")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded samples: roughly 1e9 butterfly-points for the all-core run, 1.5e8 for the single thread
+        per_line = nfft * np.log2(nfft)
+        la = int(max(8, min(n_lines, 1.6e9 / per_line)))
+        l1t = int(max(4, min(n_lines, 2.0e8 / per_line)))
+        host = iq[:((la - 1) * hop + nfft) * bps].cpu().numpy()
+        cpu_baseline = cpu_baseline_for(so, host, datatype, nfft, hop, window, la, l1t,
+                                        "segments (Hann, hop %d)" % hop if welch else "lines")
 
     # calibration outside the timed region ("calibrate with a device memcpy"): what a
     # plain device-to-device copy of the output tile moves per second on THIS box, read + write
@@ -398,10 +414,17 @@ def main() -> None:
                 ok = None
                 if rank == 0:  # the root's own rows of the gathered tile are the lines the plain step produced
                     ok = bool(torch.equal(full[l0:l1], out))
+                # the rows that CROSSED the transport: every peer's per-chunk checksums of the tile it sent (all-gathered)
+                # against the root's checksums of the rows it received -- a mis-ordered chunk or a transfer that ran ahead
+                # of its kernels shows here, not in the root's own rows
+                ver = sd.verify_gathered(full, full[l0:l1] if rank == 0 else out, total_lines, chunks, dst=0, via_cpu=rehearse)
                 peer_bytes = (total_lines - n_lines) * nfft * out.element_size()
                 gather = {"value": total_lines / gsec, "unit": "lines/s", "ms_per_step": gsec * 1e3, "chunks": chunks,
                           "steps": max(1, args.gather_steps), "GBps_into_root": peer_bytes / gsec / 1e9,
                           "root_rows_equal_plain_step": ok,
+                          "peer_rows_verified": ver["peer_rows_verified"] if ver else None,
+                          "peer_chunks_checked": ver["chunks_checked"] if ver else None,
+                          "peer_chunk_mismatches": ver["mismatches"] if ver else None,
                           "what": "compute + gather of every rank's tile on rank 0: %d chunk sends per rank on a second "
                                   "stream behind the chunk's kernels (dist.sharded_waterfall_overlapped)" % chunks}
             except Exception as e:  # the gather timing must never take the headline down with it

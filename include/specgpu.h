@@ -137,6 +137,14 @@ void *spec_stream(const spec_ctx *ctx);
  *                     CU, one of either role on every CU) and 1024 (two 512-thread workgroups per CU at 128 registers) were
  *                     measured slower and live in the variant library lib/libspecgpu_teamvar.so
  *                     (python -m spectral_analyzer_amd.build --variant teamvar); the product returns SPEC_EUNSUPPORTED
+ *   "large_single" = 1 | 0   32768-point fp32 lines (the default dispatch, "large_team" = 1): 1 (default) = ONE workgroup
+ *                     per line -- a radix-2 step in registers, then two 16384-point transforms through the same LDS buffer,
+ *                     nothing handed over between workgroups (cf32 0.45, ci16 0.43 of 8 TB/s against 0.26 / 0.10 for the
+ *                     four-step team kernel); 0 = the four-step paths of "large_team"
+ *   "multi_verify" = 0 | 1   spec_waterfall_multi / spec_welch_psd_multi with a device-resident result: 1 = every piece a
+ *                     peer context sends is checksummed on its own device before it leaves and again where it landed on
+ *                     the consumer's device; a difference is SPEC_EDEVICE and the message names piece, devices and the path
+ *                     the copy took.  Set on ctx[0] (all peers) or on one peer.  Default 0.
  *   "stage_chunk_mb" = m chunk of the host-buffer pipeline of spec_waterfall (default 64 MiB)
  *   "render_fused" = 0 | 1   spec_waterfall_render stores only the bins the image samples (default 1; 0 = full
  *                     dB tile, then the colour kernel: the two forms give identical pixels)
@@ -144,7 +152,10 @@ void *spec_stream(const spec_ctx *ctx);
  *                     slice by slice (default 256; 0 or 1 = every call is its own launch) */
 spec_status spec_set_option(spec_ctx *ctx, const char *key, int64_t value);
 /* Current value of a knob of spec_set_option, or of the read-only state "large_team_disabled" (1 once a default-mode
- * call of this context has seen its persistent large-N launch give up; "large_team" re-arms it). */
+ * call of this context has seen its persistent large-N launch give up; "large_team" re-arms it), "multi_peer_access" (the
+ * path this context's last peer copy took as a PEER of a multi call: -1 none yet, 0 staged by the runtime -- no peer
+ * access to the consumer's device --, 1 direct -- hipDeviceEnablePeerAccess succeeded --, 2 consumer on the same device)
+ * and "multi_verified" (pieces of this context whose checksums agreed in its last "multi_verify" call). */
 spec_status spec_get_option(spec_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- datatype table ------------------------------------------------------ */
@@ -223,6 +234,8 @@ void spec_shard_span(uint64_t first_line, uint64_t end_line, spec_dtype dt, uint
  *       straight into the consumer's rows with hipMemcpyPeerAsync on a second stream behind an event recorded
  *       after that piece's kernels -- the transfer of piece j overlaps the kernels of piece j + 1 (over xGMI every
  *       peer has its own link to the consumer) -- through a two-slot buffer, so no context holds a second tile.
+ *       `out` must be idle when the call is made: the peers write it from streams of their own, ordered against
+ *       nothing the caller queued earlier (on ctx[0]'s stream or elsewhere).
  * The call returns when the whole tile is in `out`.  Contexts may share a device (then they share its kernels'
  * time -- and the persistent large-N kernel of "large_team", which wants a whole device to itself, falls back to its
  * two-launch form after a bounded wait: give every context its own device); the same context may not appear twice.  On failure the first failing shard's status is returned and its

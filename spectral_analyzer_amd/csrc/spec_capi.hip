@@ -61,6 +61,15 @@ struct spec_ctx {
     void *multi_buf = nullptr; size_t multi_buf_bytes = 0;
     hipStream_t s_peer = nullptr;
     hipEvent_t ev_mdone[2] = {nullptr, nullptr}, ev_mcopied[2] = {nullptr, nullptr};
+    // "multi_verify": checksums of every piece on this (peer) device and of the rows it landed in on the consumer's
+    // device (a stream and an array over there), and what the last multi call on this context found out
+    int64_t opt_multi_verify = 0, opt_multi_verify_corrupt = 0;  // ..._corrupt (tests): damage one landed word before verifying
+    void *cks_src = nullptr; size_t cks_src_bytes = 0;
+    void *cks_dst = nullptr; size_t cks_dst_bytes = 0; int cks_dst_dev = -1;
+    hipStream_t s_verify = nullptr; int s_verify_dev = -1;
+    int64_t multi_peer_access = -1;   // -1 no peer copy yet; 0 staged by the runtime (no peer access); 1 direct (peer access
+                                      // enabled); 2 consumer on the same device
+    int64_t multi_verified = 0;       // pieces whose checksums agreed in the last verified call
     void *team_scratch = nullptr; size_t team_scratch_bytes = 0;  // spec_k_team.hip: ring slots of every team
     void *team_sync = nullptr;    size_t team_sync_bytes = 0;     //                   tickets, ring counters, abort word    // spec_welch_psd_planar_f64: interleaved copy of the burst
     // tuning / testing knobs (spec_set_option)
@@ -305,6 +314,9 @@ void spec_destroy(spec_ctx *c) {
         if (c->ev_mcopied[i]) (void)hipEventDestroy(c->ev_mcopied[i]);
     }
     if (c->s_peer) (void)hipStreamDestroy(c->s_peer);
+    if (c->s_verify) (void)hipStreamDestroy(c->s_verify);
+    (void)hipFree(c->cks_src);
+    (void)hipFree(c->cks_dst);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
         if (c->ev_done[i]) (void)hipEventDestroy(c->ev_done[i]);
@@ -345,6 +357,8 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(key, "large_team_fake_abort")) c->opt_team_fake_abort = value != 0;
     else if (!strcmp(key, "large_single")) c->opt_large_single = value != 0;
+    else if (!strcmp(key, "multi_verify")) c->opt_multi_verify = value != 0;
+    else if (!strcmp(key, "multi_verify_corrupt")) c->opt_multi_verify_corrupt = value != 0;
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
     else if (!strcmp(key, "readahead_lines")) { c->opt_readahead_lines = value < 0 ? 0 : value; c->ra.n = 0; }
     else return fail(c, SPEC_EINVAL, "spec_set_option: unknown key '%s'", key);
@@ -361,6 +375,7 @@ spec_status spec_get_option(spec_ctx *c, const char *key, int64_t *value) {
         {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single},
         {"large_block", c->opt_large_block}, {"render_fused", c->opt_render_fused}, {"readahead_lines", c->opt_readahead_lines},
         {"large_team_fake_abort", c->opt_team_fake_abort}, {"large_team_disabled", c->team_disabled ? 1 : 0},
+        {"multi_verify", c->opt_multi_verify}, {"multi_verify_corrupt", c->opt_multi_verify_corrupt}, {"multi_peer_access", c->multi_peer_access}, {"multi_verified", c->multi_verified},
     };
     for (const auto &e : tab)
         if (!strcmp(key, e.k)) { *value = e.v; return SPEC_OK; }
@@ -1049,6 +1064,61 @@ void spec_shard_span(uint64_t first_line, uint64_t end_line, spec_dtype dt, uint
     if (n_bytes) *n_bytes = end_line > first_line ? ((end_line - first_line - 1) * hop + nfft) * bps : 0;
 }
 
+// ---- peer copies of the multi-context entries: which path they take, and the "multi_verify" self-check ------------
+static const char *peer_path_name(const spec_ctx *c) {
+    return c->multi_peer_access == 2 ? "same device" : c->multi_peer_access == 1 ? "direct: peer access enabled"
+         : c->multi_peer_access == 0 ? "staged by the runtime: no peer access" : "not established";
+}
+// direct xGMI writes where the platform allows them; staged by the runtime otherwise.  Remembered on the peer context
+// ("multi_peer_access" of spec_get_option) and named in every message about a peer copy.
+static spec_status peer_path(spec_ctx *c, const spec_ctx *root) {
+    if (c->device == root->device) { c->multi_peer_access = 2; return SPEC_OK; }
+    int can = 0;
+    c->multi_peer_access = 0;
+    if (hipDeviceCanAccessPeer(&can, c->device, root->device) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) c->multi_peer_access = 1;
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    return SPEC_OK;
+}
+// After the copies have completed: the checksum of every piece where it LANDED (a kernel on the consumer's device, on a
+// stream this context keeps there) against the checksum taken on this device before it left (cks_src, device memory
+// of this context, one word per piece).
+static spec_status verify_landed(spec_ctx *c, const spec_ctx *root, const std::vector<std::pair<const void *, uint64_t>> &pieces,
+                                 const unsigned long long *cks_src, const char *who) {
+    const size_t n = pieces.size();
+    if (n == 0) return SPEC_OK;
+    std::vector<unsigned long long> src(n), dst(n);
+    HIP_TRY(c, hipMemcpyAsync(src.data(), cks_src, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipError_t e = hipSetDevice(root->device);
+    if (e == hipSuccess && (c->s_verify == nullptr || c->s_verify_dev != root->device)) {
+        if (c->s_verify) { (void)hipStreamDestroy(c->s_verify); c->s_verify = nullptr; }
+        e = hipStreamCreateWithFlags(&c->s_verify, hipStreamNonBlocking);
+        c->s_verify_dev = root->device;
+    }
+    if (e == hipSuccess && (c->cks_dst_bytes < n * 8 || c->cks_dst_dev != root->device)) {
+        (void)hipFree(c->cks_dst); c->cks_dst = nullptr; c->cks_dst_bytes = 0;
+        e = hipMalloc(&c->cks_dst, n * 8);
+        if (e == hipSuccess) { c->cks_dst_bytes = n * 8; c->cks_dst_dev = root->device; }
+    }
+    unsigned long long *d = static_cast<unsigned long long *>(c->cks_dst);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, n * 8, c->s_verify);
+    for (size_t j = 0; j < n && e == hipSuccess; ++j) e = launch_checksum(pieces[j].first, pieces[j].second, d + j, c->s_verify);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst.data(), d, n * 8, hipMemcpyDeviceToHost, c->s_verify);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->s_verify);
+    (void)hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "%s: multi_verify on device %d: %s", who, root->device, hipGetErrorString(e));
+    for (size_t j = 0; j < n; ++j)
+        if (src[j] != dst[j])
+            return fail(c, SPEC_EDEVICE, "%s: multi_verify: piece %zu of %zu (%llu bytes) sent from device %d does not match what "
+                        "landed on device %d (checksum %016llx sent, %016llx landed; %s)", who, j, n,
+                        (unsigned long long)pieces[j].second, c->device, root->device, src[j], dst[j], peer_path_name(c));
+    c->multi_verified = (int64_t)n;
+    return SPEC_OK;
+}
+
 // shard [l0, l1) of a multi-device waterfall on context c.  `src` / `src_bytes` / `src_off`: the buffer this
 // context reads (the whole host recording, or its own device span) and the byte its first line starts at.
 static spec_status multi_shard(spec_ctx *c, spec_ctx *root, bool is_root, const void *src, int src_on_device,
@@ -1070,6 +1140,7 @@ static spec_status multi_shard(spec_ctx *c, spec_ctx *root, bool is_root, const 
     if (n_chunks == 0) n_chunks = 8;
     if ((uint64_t)n_chunks > l1 - l0) n_chunks = (uint32_t)(l1 - l0);
     const uint64_t per = (l1 - l0 + n_chunks - 1) / n_chunks;  // lines per piece (the last one may be shorter)
+    const uint32_t n_pieces = (uint32_t)((l1 - l0 + per - 1) / per);
     const uint64_t slot_bytes = (per * row_bytes + 255) & ~255ull;
     spec_status st = grow(c, &c->multi_buf, &c->multi_buf_bytes, 2 * slot_bytes);
     if (st != SPEC_OK) return st;
@@ -1080,32 +1151,51 @@ static spec_status multi_shard(spec_ctx *c, spec_ctx *root, bool is_root, const 
             HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mcopied[i], hipEventDisableTiming));
         }
     }
-    if (c->device != root->device) {  // direct xGMI writes where the platform allows them; staged by the runtime otherwise
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, c->device, root->device) == hipSuccess && can) {
-            const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-        }
+    st = peer_path(c, root);
+    if (st != SPEC_OK) return st;
+    const bool verify = root->opt_multi_verify || c->opt_multi_verify;
+    c->multi_verified = 0;
+    unsigned long long *cks_src = nullptr;
+    if (verify) {
+        if ((st = grow(c, &c->cks_src, &c->cks_src_bytes, (size_t)n_pieces * 8)) != SPEC_OK) return st;
+        cks_src = static_cast<unsigned long long *>(c->cks_src);
+        HIP_TRY(c, hipMemsetAsync(cks_src, 0, (size_t)n_pieces * 8, c->stream));
     }
+    // (Any failure inside the loop leaves it by `break`: the two synchronisations below must run before this function
+    // returns -- peer copies into `out` may still be in flight, and the slots and events are reused by the next call.)
+    hipError_t le = hipSuccess;
     uint32_t j = 0;
-    for (uint64_t a = l0; a < l1; a += per, ++j) {
+    for (uint64_t a = l0; a < l1 && st == SPEC_OK && le == hipSuccess; a += per, ++j) {
         const uint64_t b = a + per < l1 ? a + per : l1;
         const int slot = (int)(j & 1u);
         uint8_t *buf = static_cast<uint8_t *>(c->multi_buf) + slot * slot_bytes;
-        if (j >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_mcopied[slot], 0));  // piece j - 2 has left the slot
+        if (j >= 2 && (le = hipStreamWaitEvent(c->stream, c->ev_mcopied[slot], 0)) != hipSuccess) break;  // piece j - 2 has left the slot
         st = waterfall_impl(c, src, src_on_device, src_bytes, src_off + (a - l0) * hop * bps, dt, nfft, hop, b - a, window,
                             out_fmt, -150.0, buf, 1, nullptr, 0);
         if (st != SPEC_OK) break;
-        HIP_TRY(c, hipEventRecord(c->ev_mdone[slot], c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->s_peer, c->ev_mdone[slot], 0));
-        HIP_TRY(c, hipMemcpyPeerAsync(static_cast<uint8_t *>(out) + a * row_bytes, root->device, buf, c->device,
-                                      (b - a) * row_bytes, c->s_peer));
-        HIP_TRY(c, hipEventRecord(c->ev_mcopied[slot], c->s_peer));
+        if (verify && (le = launch_checksum(buf, (b - a) * row_bytes, cks_src + j, c->stream)) != hipSuccess) break;
+        if ((le = hipEventRecord(c->ev_mdone[slot], c->stream)) != hipSuccess) break;
+        if ((le = hipStreamWaitEvent(c->s_peer, c->ev_mdone[slot], 0)) != hipSuccess) break;
+        if ((le = hipMemcpyPeerAsync(static_cast<uint8_t *>(out) + a * row_bytes, root->device, buf, c->device,
+                                     (b - a) * row_bytes, c->s_peer)) != hipSuccess) break;
+        if ((le = hipEventRecord(c->ev_mcopied[slot], c->s_peer)) != hipSuccess) break;
     }
     const hipError_t e1 = hipStreamSynchronize(c->s_peer), e2 = hipStreamSynchronize(c->stream);
     if (st != SPEC_OK) return st;
+    if (le != hipSuccess) return fail(c, SPEC_EDEVICE, "peer copy (%s): %s", peer_path_name(c), hipGetErrorString(le));
     if (e1 != hipSuccess || e2 != hipSuccess)
-        return fail(c, SPEC_EDEVICE, "peer copy: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        return fail(c, SPEC_EDEVICE, "peer copy (%s): %s", peer_path_name(c), hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    if (verify) {
+        std::vector<std::pair<const void *, uint64_t>> pieces;
+        for (uint64_t a = l0; a < l1; a += per)
+            pieces.emplace_back(static_cast<const uint8_t *>(out) + a * row_bytes, ((a + per < l1 ? a + per : l1) - a) * row_bytes);
+        if (c->opt_multi_verify_corrupt) {  // tests: one word of the LAST piece is damaged where it landed
+            c->opt_multi_verify_corrupt = 0;
+            const uint32_t bad = 0x7FC0DEADu;
+            HIP_TRY(c, hipMemcpy(const_cast<void *>(pieces.back().first), &bad, 4, hipMemcpyHostToDevice));
+        }
+        return verify_landed(c, root, pieces, cks_src, "spec_waterfall_multi");
+    }
     return SPEC_OK;
 }
 
@@ -1608,9 +1698,22 @@ spec_status spec_welch_psd_multi(spec_ctx *const *ctx, uint32_t n_ctx, const voi
         if (status[r] != SPEC_OK || !out_on_device) return;
         Enter g(c);
         hipError_t e = hipSuccess;
-        if (via_peer) e = hipMemcpyPeerAsync(psd_out + a * nfft, root->device, dest, c->device, bytes, c->stream);
+        const bool verify = via_peer && (root->opt_multi_verify || c->opt_multi_verify);
+        if (via_peer) {
+            if ((status[r] = peer_path(c, root)) != SPEC_OK) return;
+            c->multi_verified = 0;
+            if (verify) {
+                if ((status[r] = grow(c, &c->cks_src, &c->cks_src_bytes, 8)) != SPEC_OK) return;
+                e = hipMemsetAsync(c->cks_src, 0, 8, c->stream);
+                if (e == hipSuccess) e = launch_checksum(dest, bytes, static_cast<unsigned long long *>(c->cks_src), c->stream);
+            }
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(psd_out + a * nfft, root->device, dest, c->device, bytes, c->stream);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) status[r] = fail(c, SPEC_EDEVICE, "peer copy: %s", hipGetErrorString(e));
+        if (e != hipSuccess) { status[r] = fail(c, SPEC_EDEVICE, "peer copy (%s): %s", peer_path_name(c), hipGetErrorString(e)); return; }
+        if (verify)
+            status[r] = verify_landed(c, root, {{psd_out + a * nfft, (uint64_t)bytes}}, static_cast<unsigned long long *>(c->cks_src),
+                                      "spec_welch_psd_multi");
     };
     std::vector<std::thread> th;
     for (uint32_t r = 1; r < n_ctx; ++r) {

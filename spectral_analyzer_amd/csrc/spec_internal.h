@@ -94,6 +94,8 @@ hipError_t launch_v2_spectro_sel(const WfArgs &w, int log2n, uint32_t run, const
 hipError_t launch_v2_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t wgs_per_unit, hipStream_t s);
 
 hipError_t launch_fill(void *out, uint64_t n_elems, double value, int is_f64, hipStream_t s);
+// *out += sum_i word_i * (2 i + 1) mod 2^64 over the n_bytes / 4 words at p ("multi_verify")
+hipError_t launch_checksum(const void *p, uint64_t n_bytes, unsigned long long *out, hipStream_t s);
 // slabs_f64 / out_f64: element type of the slabs / of psd_out
 hipError_t launch_welch_finalize(const void *partial, int slabs_f64, uint32_t n_psd, uint32_t n_slabs,
                                  uint32_t nfft, double norm, int db, void *psd_out, int out_f64, hipStream_t s);

@@ -19,6 +19,26 @@ hipError_t launch_fill(void *out, uint64_t n, double value, int is_f64, hipStrea
     return hipGetLastError();
 }
 
+// Position-weighted checksum of a run of 32-bit words, added (mod 2^64) into *out: sum_i word_i * (2 i + 1).  Used by
+// the "multi_verify" option of spec_waterfall_multi / spec_welch_psd_multi: the same number over a piece before it
+// leaves a peer's device and over the rows it landed in on the consumer's device (a moved, truncated or stale piece
+// changes it; the order of the partial sums does not).
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t *__restrict__ w, uint64_t n, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        acc += (unsigned long long)w[i] * (2ull * i + 1ull);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+hipError_t launch_checksum(const void *p, uint64_t n_bytes, unsigned long long *out, hipStream_t s) {
+    const uint64_t n = n_bytes / 4;
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(checksum_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint32_t *>(p), n, out);
+    return hipGetLastError();
+}
+
 // Sum the partial slabs of each PSD, scale, fftshift, optional 10 log10(P + 1e-20).  A block
 // owns 32 bins; its 8 lanes per bin each sum every 8th slab and are combined in lane order, so
 // the result does not depend on scheduling (bitwise reproducible, no atomics) while a single

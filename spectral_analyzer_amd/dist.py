@@ -149,6 +149,50 @@ def sharded_waterfall_overlapped(compute_rows: Callable[[int, int, torch.Tensor]
     return full
 
 
+def chunk_checksums(rows: torch.Tensor, first_line: int, bounds) -> torch.Tensor:
+    """One 64-bit checksum per chunk ``(a, b)`` of ``bounds`` over ``rows`` (= lines ``first_line ...``): the rows' bit
+    patterns summed as integers, every row weighted by its GLOBAL line number + 1, modulo 2^64.  Exact (no floating
+    point), independent of how the sum is split up, and sensitive to a row that is missing, stale or in the wrong place."""
+    bits = rows.view(torch.int32 if rows.element_size() == 4 else torch.int64)
+    out = torch.zeros(len(bounds), dtype=torch.int64, device=rows.device)
+    for j, (a, b) in enumerate(bounds):
+        if b > a:
+            w = torch.arange(a + 1, b + 1, dtype=torch.int64, device=rows.device)
+            out[j] = (bits[a - first_line:b - first_line].to(torch.int64).sum(dim=1) * w).sum()
+    return out
+
+
+def verify_gathered(full: Optional[torch.Tensor], mine: torch.Tensor, total: int, n_chunks: int, dst: int = 0,
+                    group: Optional[dist.ProcessGroup] = None, via_cpu: bool = False) -> Optional[dict]:
+    """Did the rows that CROSSED the transport arrive?  Every rank all-gathers the per-chunk checksums of the tile it
+    computed (``mine``: its own ``[lines_r, nfft]`` rows -- on the root, its rows of ``full``); the root recomputes them
+    over the rows it RECEIVED in ``full`` and compares, peer by peer and chunk by chunk.  Returns on the root
+    ``{"peer_rows_verified": bool, "chunks_checked": n, "mismatches": [(rank, chunk), ...]}``, None elsewhere.
+    ``via_cpu``: exchange the checksums as CPU tensors (gloo rehearsal with GPU tiles)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    l0, l1 = shard_lines(total, world, rank)
+    sent = chunk_checksums(mine, l0, chunk_bounds(l0, l1, n_chunks))
+    sent = sent.cpu() if via_cpu else sent
+    got = [torch.zeros_like(sent) for _ in range(world)]
+    dist.all_gather(got, sent, group=group)
+    if rank != dst:
+        return None
+    bad, checked = [], 0
+    for r in range(world):
+        if r == dst:
+            continue
+        r0, r1 = shard_lines(total, world, r)
+        bounds = chunk_bounds(r0, r1, n_chunks)
+        landed = chunk_checksums(full[r0:r1], r0, bounds).cpu()
+        theirs = got[r].cpu()
+        for j, (a, b) in enumerate(bounds):
+            if b > a:
+                checked += 1
+                if int(landed[j]) != int(theirs[j]):
+                    bad.append((r, j))
+    return {"peer_rows_verified": not bad, "chunks_checked": checked, "mismatches": bad}
+
+
 def sharded_waterfall(compute_tile: Callable[[int, int], torch.Tensor], total: int, nfft: int,
                       gather_to: Optional[int] = 0, group: Optional[dist.ProcessGroup] = None):
     """Run ``compute_tile(l0, l1)`` for this rank's line range and gather.

@@ -72,6 +72,19 @@ def _worker(rank, world, port, total, q):
             assert chunked is own and torch.equal(chunked, full) and torch.equal(piped, full)
         else:
             assert chunked is None and piped is None
+        # the self-check of bench.py's gather record: checksums of what every peer SENT against what the root RECEIVED
+        v = sd.verify_gathered(piped, local if rank else piped[l0:l1], total, 4, dst=0)
+        if rank == 0:
+            n_peer_chunks = sum(1 for r in range(1, world) for a, b in sd.chunk_bounds(*sd.shard_lines(total, world, r), 4) if b > a)
+            assert v == {"peer_rows_verified": True, "chunks_checked": n_peer_chunks, "mismatches": []}
+            if total > 1:                                   # a row of the last peer lands one line too early: noticed
+                r0, r1 = sd.shard_lines(total, world, world - 1)
+                piped[r0:r1] = torch.roll(piped[r0:r1], 1, dims=0) if r1 - r0 > 1 else piped[r0:r1] + 1.0
+        else:
+            assert v is None
+        v = sd.verify_gathered(piped, local if rank else piped[l0:l1], total, 4, dst=0)
+        if rank == 0 and total > 1:
+            assert v["peer_rows_verified"] is False and all(r == world - 1 for r, _ in v["mismatches"]) and v["mismatches"]
 
         w = so.np_window(nfft, so.WIN_HANN)
         psd = sd.sharded_welch(partial_power, total, 1.0 / (1.0 * (w ** 2).sum()))

@@ -696,6 +696,27 @@ def test_waterfall_multi_equals_the_single_context_tile(svc, oracle, datatype, n
         out.fill_(float("nan"))
         sa.compute_waterfall_multi(services, iq, 0, nfft, datatype, n_lines + extra, hop=hop, out_fmt=fmt, out=out)
         assert np.array_equal(out.cpu().numpy(), one)
+        # "multi_verify": every piece checksummed on the peer's device before it leaves and where it landed on the
+        # consumer's; set on ctx[0] it covers every peer.  The peers report the path their copies took.
+        svc.set_option("multi_verify", 1)
+        try:
+            out.fill_(float("nan"))
+            sa.compute_waterfall_multi(services, shards, 0, nfft, datatype, n_lines + extra, hop=hop, out_fmt=fmt, out=out,
+                                       n_bytes=iq.size, n_chunks=5)
+            assert np.array_equal(out.cpu().numpy(), one)
+            for r, p in enumerate(peers, start=1):
+                l0, l1 = sa.shard_lines(n_lines, 3, r)
+                assert p.get_option("multi_verified") == min(5, l1 - l0)    # pieces of this peer, all agreed
+                assert p.get_option("multi_peer_access") == 2               # consumer on the same device (one-GPU box)
+            assert svc.get_option("multi_verified") == 0 and svc.get_option("multi_peer_access") == -1   # the consumer sends nothing
+            # and it does notice: one word of peer 2's last piece damaged where it landed ("multi_verify_corrupt", tests only)
+            if sa.shard_lines(n_lines, 3, 2)[1] > sa.shard_lines(n_lines, 3, 2)[0]:
+                peers[1].set_option("multi_verify_corrupt", 1)
+                with pytest.raises(RuntimeError, match="multi_verify: piece .* does not match what landed .* same device"):
+                    sa.compute_waterfall_multi(services, shards, 0, nfft, datatype, n_lines + extra, hop=hop, out_fmt=fmt, out=out,
+                                               n_bytes=iq.size, n_chunks=5)
+        finally:
+            svc.set_option("multi_verify", 0)
         with pytest.raises(ValueError):                                     # the same context twice
             sa.compute_waterfall_multi([svc, svc], iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=fmt)
         with pytest.raises(ValueError):                                     # the reference's error behaviour is kept
@@ -765,6 +786,15 @@ def test_welch_multi_equals_the_single_context_batch(svc, oracle, datatype, nfft
             out = torch.full((n_psd, nfft), float("nan"), dtype=torch.float32, device="cuda")
             _, got = sa.welch_psd_multi(services, shards, 0, datatype, fs, nfft, hop, n_seg, n_psd, per * bps, db=db, out=out)
             assert got is out and same(out.cpu().numpy(), one, db)
+            peers[0].set_option("multi_verify", 1)                          # on ONE peer: its rows only
+            try:
+                out.fill_(float("nan"))
+                sa.welch_psd_multi(services, shards, 0, datatype, fs, nfft, hop, n_seg, n_psd, per * bps, db=db, out=out)
+                assert same(out.cpu().numpy(), one, db)
+                a, b = sa.shard_lines(n_psd, 3, 1)
+                assert peers[0].get_option("multi_verified") == (1 if b > a else 0) and peers[1].get_option("multi_verified") == 0
+            finally:
+                peers[0].set_option("multi_verify", 0)
         with pytest.raises(ValueError):                                     # the same context twice
             sa.welch_psd_multi([svc, svc], iq, 0, datatype, fs, nfft, hop, n_seg, n_psd, per * bps)
         with pytest.raises(IndexError):                                     # spec_welch_psd's range error, from a shard
