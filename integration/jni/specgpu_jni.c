@@ -101,16 +101,22 @@ JNIEXPORT void JNICALL JNI_FN(nativeWaterfallMulti)(JNIEnv *env, jclass k, jlong
     void *base = (*env)->GetDirectBufferAddress(env, buffer);
     jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
     if (!base || cap < 0) { throw_shim(env, "computeWaterfallMulti: not a direct buffer"); return; }
-    if (nfft < 0 || nLines < 0 || (jlong)(*env)->GetArrayLength(env, out) < nLines * (jlong)nfft) {
+    if (startByte < 0 || hop < 1 || nfft < 1 || nLines < 0) { throw_shim(env, "computeWaterfallMulti: negative startByte / nLines, or hop / nfft < 1"); return; }
+    /* overflow-safe: nLines * nfft may not fit a jlong */
+    if (nLines > (jlong)(*env)->GetArrayLength(env, out) / (jlong)nfft) {
         throw_shim(env, "computeWaterfallMulti: out is shorter than nLines * nfft");
         return;
     }
     spec_ctx *ctx[64];
     jlong *h = (*env)->GetLongArrayElements(env, handles, NULL);
+    if (!h) return;  /* OutOfMemoryError is pending */
     for (jsize i = 0; i < n; ++i) ctx[i] = (spec_ctx *)(intptr_t)h[i];
     (*env)->ReleaseLongArrayElements(env, handles, h, JNI_ABORT);
+    for (jsize i = 0; i < n; ++i)
+        if (!ctx[i]) { throw_shim(env, "computeWaterfallMulti: a service is closed (null handle)"); return; }
     const void *iq[1] = {base};
     jfloat *o = (*env)->GetFloatArrayElements(env, out, NULL);
+    if (!o) return;
     spec_status st = spec_waterfall_multi(ctx, (uint32_t)n, iq, 0, (uint64_t)cap, (uint64_t)startByte, (spec_dtype)dtype,
                                           (uint32_t)nfft, (uint32_t)hop, (uint64_t)nLines, (spec_window)window,
                                           SPEC_OUT_DB20_F32, eofFill, o, 0, 0);
@@ -152,19 +158,24 @@ JNIEXPORT void JNICALL JNI_FN(nativeWelchMulti)(JNIEnv *env, jclass k, jlongArra
     void *base = (*env)->GetDirectBufferAddress(env, buffer);
     jlong cap = (*env)->GetDirectBufferCapacity(env, buffer);
     if (!base || cap < 0) { throw_shim(env, "welchPsdMulti: not a direct buffer"); return; }
-    if (nfft < 0 || nPsd < 0 || startByte < 0 || psdStrideBytes < 0 || (*env)->GetArrayLength(env, freq) < nfft ||
-        (jlong)(*env)->GetArrayLength(env, psd) < (jlong)nPsd * nfft) {
-        throw_shim(env, "welchPsdMulti: freq is shorter than nfft or psd than nPsd * nfft");
+    if (nfft < 1 || nPsd < 0 || startByte < 0 || psdStrideBytes < 0 || hop < 1 || nSeg < 0 || (*env)->GetArrayLength(env, freq) < nfft ||
+        (jlong)nPsd > (jlong)(*env)->GetArrayLength(env, psd) / (jlong)nfft) {
+        throw_shim(env, "welchPsdMulti: negative argument, or freq is shorter than nfft or psd than nPsd * nfft");
         return;
     }
     spec_ctx *ctx[64];
     jlong *h = (*env)->GetLongArrayElements(env, handles, NULL);
+    if (!h) return;  /* OutOfMemoryError is pending */
     for (jsize i = 0; i < n; ++i) ctx[i] = (spec_ctx *)(intptr_t)h[i];
     (*env)->ReleaseLongArrayElements(env, handles, h, JNI_ABORT);
+    for (jsize i = 0; i < n; ++i)
+        if (!ctx[i]) { throw_shim(env, "welchPsdMulti: a service is closed (null handle)"); return; }
     const void *iq[1] = {base};
     const uint64_t n_bytes[1] = {(uint64_t)cap};
     jdouble *f = (*env)->GetDoubleArrayElements(env, freq, NULL);
+    if (!f) return;
     jfloat *p = (*env)->GetFloatArrayElements(env, psd, NULL);
+    if (!p) { (*env)->ReleaseDoubleArrayElements(env, freq, f, JNI_ABORT); return; }
     spec_status st = spec_welch_psd_multi(ctx, (uint32_t)n, iq, 0, n_bytes, (uint64_t)startByte, (uint64_t)psdStrideBytes,
                                           (uint32_t)nPsd, (spec_dtype)dtype, (uint32_t)nfft, (uint32_t)hop, (uint32_t)nSeg,
                                           (spec_window)window, (spec_psd_scaling)scaling, fs, db ? 1 : 0, f, p, 0);

@@ -54,11 +54,11 @@ def test_product_library_refuses_the_experiment_geometries(svc, oracle):
     import torch
     if VARIANT:
         pytest.skip("variant library")
-    iq = torch.from_numpy(oracle.synth_iq("cf32_le", 1, 0, 65 * 16384 + 32768)).cuda()
+    iq = torch.from_numpy(oracle.synth_iq("cf32_le", 1, 0, 65 * 16384 + 65536)).cuda()
     try:
         svc.set_option("large_wg", 256)
-        with pytest.raises(NotImplementedError, match="experiment geometry"):
-            svc.compute_waterfall(iq, 0, 32768, "cf32_le", 65, hop=16384)
+        with pytest.raises(NotImplementedError, match="experiment geometry"):   # (65536 points: 32768-point fp32 lines no
+            svc.compute_waterfall(iq, 0, 65536, "cf32_le", 65, hop=16384)       #  longer take the team kernel by default)
     finally:
         svc.set_option("large_wg", 512)
 
