@@ -140,6 +140,7 @@ def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nf
     default dispatch it leaves the team kernel's result alone (its guard reads the abort word, which stays 0)."""
     import torch
     iq = torch.from_numpy(oracle.synth_iq(datatype, 31, 3, (n_lines - 1) * hop + nfft)).cuda()
+    svc.set_option("large_single", 0)      # (32768-point fp32 lines: the four-step paths are what this test is about)
     try:
         out = {}
         for mode in (0, 3, 2, 1):
@@ -151,6 +152,7 @@ def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nf
         assert bool((out[3][n_lines] == -150.0).all())
     finally:
         svc.set_option("large_team", 1)
+        svc.set_option("large_single", 1)
 
 
 def test_a_context_stops_trying_the_team_kernel_after_one_abort(oracle):
