@@ -61,6 +61,19 @@ VARIANTS = {
     "tPROF": (["-DSPEC_TEAM_PROF"], ["spec_k_team.hip", "spec_capi.hip"]),
     # experiments on the single-workgroup 32768-point kernel: how many cf32 samples of the next line are requested
     # beside the second transform (tools/bench_v2h.py)
+    # round-4 experiment: wave-autonomous sides of the team kernel (fp64 lines)
+    "tWA": (["-DSPEC_TEAM_WA"], ["spec_k_team.hip"]),
+    "tWAnt": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_LD=0"], ["spec_k_team.hip"]),
+    # ablations of it (results wrong by construction): column side alone; without its slot stores; without its arithmetic
+    "tWAa": (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
+    "tWAb": (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT"], ["spec_k_team.hip"]),
+    "tWAc": (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT", "-DSPEC_ABL_TEAM_NOFFT"], ["spec_k_team.hip"]),
+    "tWAs": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0"], ["spec_k_team.hip"]),
+    "tWA1": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=1"], ["spec_k_team.hip"]),
+    "tWA2": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2"], ["spec_k_team.hip"]),
+    "tWA1a": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=1", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
+    "tWA2a": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
+    "tOLDa": (["-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
     "v2hpf0": (["-DV2H_PF=0"], ["spec_k_v2h.hip"]),
     "v2hpf8": (["-DV2H_PF=8"], ["spec_k_v2h.hip"]),
     "v2hpf20": (["-DV2H_PF=20"], ["spec_k_v2h.hip"]),

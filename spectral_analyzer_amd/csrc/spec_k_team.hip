@@ -109,6 +109,26 @@ __device__ __forceinline__ bool team_wait(const uint32_t *ctr, uint32_t target, 
     return ok != 0;
 }
 
+// The same wait for ONE wave (wave-autonomous sides, SPEC_TEAM_WA): lane 0 polls, the verdict is broadcast; no barrier.
+__device__ __forceinline__ bool wave_wait(const uint32_t *ctr, uint32_t target, uint32_t *sync) {
+    int ok = 1;
+    if ((threadIdx.x & 63) == 0) {
+        if ((int32_t)(ld_sc1(ctr) - target) < 0) {
+            const long long t0 = wall_clock64();
+            uint32_t spins = 0;
+            while ((int32_t)(ld_sc1(ctr) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 31u) == 0 && (ld_sc1(sync + TS_ABORT) != 0 || wall_clock64() - t0 > TEAM_SPIN_LIMIT)) {
+                    ok = 0;
+                    break;
+                }
+            }
+            if (!ok) __hip_atomic_store(sync + TS_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
+
 template <typename R> __device__ __forceinline__ void ctw(cx<R> &u, const cx<R> w) { u = cmul(u, w); }
 
 // An LDS exchange whose writes and reads stay inside one wave needs no s_barrier: a wave's DS operations complete in
@@ -268,9 +288,13 @@ template <int POLICY> __device__ __forceinline__ void glds16(const void *gsrc, u
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    else
+    else if constexpr (POLICY == 1)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else  // 2: plain (cached): a row of the recording is requested by several waves in pieces, one after the other
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 // one counter word (lane 0 of the calling branch) to LDS lds_dst, sc1
@@ -383,7 +407,12 @@ template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *ou
 // DENSE: two workgroups per CU (four waves per SIMD, 128 registers each) that hide latency by occupancy: no
 // landing strips, the plain forms of both sides.
 template <typename R, int L1, int L2, int WG, bool DENSE> struct TeamLds {
+#ifdef SPEC_TEAM_WA
+    // wave-autonomous column side: line buffers padded by one element per eight (WSL = M + M / 8 elements per column)
+    static constexpr size_t A = (size_t)TP<L1, WG>::C * (TP<L1, WG>::M + TP<L1, WG>::M / 8) + TP<L1, WG>::M;
+#else
     static constexpr size_t A = (size_t)TP<L1, WG>::C * TP<L1, WG>::SL + TP<L1, WG>::M;
+#endif
     static constexpr size_t B = (size_t)TP<L2, WG>::C * TP<L2, WG>::SL + TP<L2, WG>::M;
     static constexpr size_t MAIN = A > B ? A : B;
     static constexpr bool PIPE = !DENSE;
@@ -411,7 +440,25 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     __shared__ int s_flag, s_next;
     __shared__ uint32_t s_info[4];
     __shared__ uint32_t s_arrive;  // column side: waves whose stores of the pending line are in L2 (monotonic)
+    __shared__ uint32_t s_arrive_slot[TEAM_RING_MAX];  // wave-autonomous column side: the same count per ring slot
     constexpr uint32_t WAVES = WG / 64;
+#ifndef SPEC_TEAM_WA_DEEP
+#define SPEC_TEAM_WA_DEEP 1  // wave-autonomous column side at 50 % overlap: requests two lines ahead
+#endif
+#ifndef SPEC_TEAM_WA_ANN
+#define SPEC_TEAM_WA_ANN 0  // where a wave of the wave-autonomous column side waits for its previous line's stores and
+#endif                      // announces: 0 behind pass 0's exchange write, 1 behind pass 1, 2 behind the whole transform
+#ifndef SPEC_TEAM_WA_LD
+#define SPEC_TEAM_WA_LD 2  // cache policy of the wave-autonomous column side's requests (glds16): 0 nt, 2 plain
+#endif
+#ifdef SPEC_TEAM_WA
+    // wave-autonomous column side (fp64 lines, samples as they are in memory): every WAVE announces its own two columns
+    constexpr bool WA_COL = sizeof(R) == 8 && DIRECT && !DENSE && WG == 512;
+#else
+    constexpr bool WA_COL = false;
+#endif
+    constexpr uint32_t APT = 1u;  // announcements (adds to doneA) per column tile and line (one per WAVE was tried: 128 adds per
+                                  // line and team on one L2 word -- 35 ms per cfg5 step against 13.3)
     double *s_dbt = reinterpret_cast<double *>(smem + LD::DBT_OFF);
 #ifdef SPEC_TEAM_PROF
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // phase stamps of lane 0 (tools/team_prof.py)
@@ -428,6 +475,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     // would still come out in equal numbers, only the pairing would be imperfect.
     constexpr bool PAIRED = WG == 256;
     if (tid == 0) s_arrive = 0;
+    if (tid < TEAM_RING_MAX) s_arrive_slot[tid] = 0;
     if (tid == 0) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -537,7 +585,8 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         const uint32_t c0 = member * PA::C;
         const int q0 = tid % PA::C, t0 = tid / PA::C;  // loads: columns fastest (contiguous samples)
         const int t1 = tid % PA::T, q1 = tid / PA::T;  // stores: k1 fastest (contiguous intermediate)
-        cx<R> *tab = lds + (size_t)PA::C * PA::SL;
+        constexpr int WSL = PA::M + PA::M / 8;  // wave-autonomous form: padded column buffers (below)
+        cx<R> *tab = lds + (size_t)PA::C * (WA_COL ? WSL : PA::SL);
         for (int e = tid; e < N1; e += WG) tab[e] = static_cast<const cx<R> *>(a.tw1)[e];
         const R *__restrict__ win = static_cast<const R *>(a.win);
         // inter-step twiddle W_N^(n2 k1), k1 = t1 + m T: W^(n2 t1) (W^(n2 T))^m, recurrence in fp64
@@ -582,6 +631,241 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 }
             }
         };
+        if constexpr (WA_COL) {
+            if (win == nullptr) {
+                // ---- wave-autonomous form (round 4) ----------------------------------------------------------------------
+                // The workgroup's 16 columns are dealt to its 8 waves, two each; a column's 32 threads are one half of a
+                // wave, so ALL of a line's exchanges stay inside the wave and nothing in the line loop is a workgroup
+                // barrier: the eight waves of a CU drift apart and fill each other's LDS, vector-memory and arithmetic
+                // phases instead of walking them in lock step (one workgroup's waves in step leave the vector
+                // ALU 0.36 busy).  Every wave requests its own two columns (32- or 64-byte pieces: CPW adjacent lanes = one row of its
+                // columns), keeps line i + 1's upper half in flight behind line i's transform, stores and announces its own
+                // columns, polls the ring for itself (a word of its own), and the last wave to see its stores done announces the tile.
+                constexpr uint32_t CPW = 64u / PA::T;                      // columns per wave: 2 (256-point columns) or 4 (128-point)
+                const uint32_t wq = lane / PA::T, wt = lane % PA::T;       // transform role: column wq of the wave's, butterfly index wt
+                const uint32_t ncol = c0 + CPW * wave + wq;                // n2 of this lane's column
+                cx<R> *colbuf = lds + (size_t)(CPW * wave + wq) * WSL;     // that column's line buffer: this wave's alone
+                // Exchanges in the (column, butterfly) lane order: a column's threads are NEIGHBOURS, so pass 0's writes
+                // (element 8 t + r: lanes 128 bytes apart) would all hit the same four banks -- measured 35 ms per cfg5
+                // step.  One pad element per eight, index a -> a + (a >> 3): eight neighbouring lanes then cover all 32
+                // banks once on every write and read of both exchanges.
+                auto pad8 = [](int a) { return a + (a >> 3); };
+                auto wstore0 = [&](const cx<R> (&x)[TE]) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) colbuf[9 * (int)wt + r] = x[r];            // pad8(8 t + r) = 9 t + r
+                };
+                auto wstore1 = [&](const cx<R> (&x)[TE]) {
+                    const int k = (int)wt & 7, j = ((int)wt - k) * 8 + k;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) colbuf[pad8(j) + 9 * r] = x[r];            // pad8(j + 8 r): (j + 8 r) >> 3 = (j >> 3) + r
+                };
+                auto wload = [&](cx<R> (&x)[TE]) {
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) x[m] = colbuf[pad8((int)wt + m * PA::T)];
+                };
+                const uint32_t dk = lane / CPW, dcol = c0 + CPW * wave + lane % CPW;  // request role: row dk (+ T m) of column dcol
+                constexpr int NLD = HALF ? NEWH : TE;
+                auto issue_rows = [&](uint32_t line, auto first_tag, auto end_tag) {
+                    constexpr int FIRST = decltype(first_tag)::value, END = decltype(end_tag)::value;
+                    const uint8_t *src = a.iq + (uint64_t)line * a.hop * sizeof(cx<R>);
+#pragma unroll
+                    for (int m = FIRST; m < END; ++m)
+                        glds16<SPEC_TEAM_WA_LD>(src + (uint64_t)((dk + (uint32_t)PA::T * m) * N2 + dcol) * sizeof(cx<R>), land_addr + 1024u * m);
+                };
+                auto issue_next = [&](uint32_t i_next) {
+                    const uint32_t ic = i_next < my_lines ? i_next : my_lines - 1;  // tail: a valid line again, unused
+                    const uint32_t ln = line_of(ic);
+                    if constexpr (HALF) {
+                        if (!follows(ic)) issue_rows(ln, std::integral_constant<int, 0>{}, std::integral_constant<int, NEWH>{});
+                        issue_rows(ln, std::integral_constant<int, NEWH>{}, std::integral_constant<int, TE>{});
+                    } else {
+                        issue_rows(ln, std::integral_constant<int, 0>{}, std::integral_constant<int, TE>{});
+                    }
+                };
+                const cx<R> *mine = land + CPW * wt + wq;                  // element (row wt + T m) of my column at mine[64 m]
+                __syncthreads();  // table visible (set-up: the only workgroup barrier of this side)
+                PassTw<R, L1, WG> wtw;
+                wtw.load((int)wt, tab);
+                const cx<double> ww0 = twn[ncol * wt], wwstep = twn[ncol * (uint32_t)PA::T];
+                cx<R> cur[TE];
+                issue_rows(line_of(0), std::integral_constant<int, 0>{}, std::integral_constant<int, TE>{});
+                vm_wait<0>();
+#pragma unroll
+                for (int m = 0; m < TE; ++m) cur[m] = mine[64 * m];
+                wave_sync();
+                uint32_t pending = NONE;
+#if SPEC_TEAM_WA_DEEP
+                if constexpr (HALF) {
+                    if (blk == 0) {
+                        // ---- 50 % overlap, contiguous lines: the new upper half of a line is requested TWO lines ahead.  One line
+                        // ahead, a wave's loop time is bounded by the memory latency (its stores and the next requests sit in one
+                        // in-order queue, and the next line cannot start before they are back: measured 1.9 us per line with the
+                        // slot stores removed, 3.9 with them, against 1.3 us of arithmetic).  The strip is half empty at 50 %
+                        // overlap: lines alternate between its two halves (instruction slots 4 p .. 4 p + 3, p = line & 1).
+                        auto issue_upper = [&](uint32_t i_line) {
+                            const uint32_t ic = i_line < my_lines ? i_line : my_lines - 1;  // tail: a valid line again, unused
+                            const uint8_t *src = a.iq + (uint64_t)line_of(ic) * a.hop * sizeof(cx<R>);
+                            const uint32_t base = land_addr + 1024u * NEWH * (i_line & 1u);
+#pragma unroll
+                            for (int m = 0; m < NEWH; ++m)
+                                glds16<SPEC_TEAM_WA_LD>(src + (uint64_t)((dk + (uint32_t)PA::T * (m + NEWH)) * N2 + dcol) * sizeof(cx<R>), base + 1024u * m);
+                        };
+                        issue_upper(1);
+                        issue_upper(2);
+#ifdef SPEC_ABL_TEAM_NOSLOT
+                        constexpr int YOUNGER = NEWH;           // ablation build: no slot stores in the queue
+#else
+                        constexpr int YOUNGER = TE + NEWH;      // behind line i + 1's requests: the stores of line i - 1, line i + 2's requests
+#endif
+                        for (uint32_t i = 0; i < my_lines; ++i) {
+                            const uint32_t slot = i % a.ring, round = i / a.ring;
+                            cx<R> v[TE];
+#pragma unroll
+                            for (int m = 0; m < TE; ++m) v[m] = cur[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
+                            dft8(v);
+#endif
+                            wstore0(v);
+                            wave_sync();
+                            wload(v);
+                            wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                            wtw.pass1(v);
+#endif
+                            wstore1(v);
+                            wave_sync();
+                            wload(v);
+                            wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                            wtw.pass2(v);
+#endif
+                            {   // inter-step twiddle W_N^(n2 k1), k1 = wt + T m: recurrence in fp64
+                                cx<double> w = ww0;
+#pragma unroll
+                                for (int m = 0; m < TE; ++m) {
+                                    v[m] = cmul(v[m], w);
+                                    w = cmul(w, wwstep);
+                                }
+                            }
+                            // line i + 1's upper half was requested two lines ago; what is younger may stay in flight
+                            if (i == 0) vm_wait<NEWH>();
+                            else vm_wait<YOUNGER>();
+                            {
+                                const cx<R> *up = mine + 64 * NEWH * ((i + 1) & 1u);
+#pragma unroll
+                                for (int m = 0; m < NEWH; ++m) { cur[m] = cur[m + NEWH]; cur[m + NEWH] = up[64 * m]; }
+                            }
+                            wave_sync();
+                            // the stores of line i - 1 (older than line i + 2's requests) have had a whole line: announce it
+                            vm_wait<NEWH>();
+                            if (lane == 0 && pending != NONE && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((i - 1) / a.ring + 1))
+                                __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                            if (round != 0 && (pending == NONE || (int32_t)(pland[2u * wave + (i & 1u)] - NT * round) < 0) &&
+                                !wave_wait(ring + 32 * slot + 16, NT * round, sync)) return;
+#endif
+                            {
+                                const uint32_t word = __builtin_amdgcn_readfirstlane(pland_addr + 8u * wave + 4u * ((i + 1) & 1u));
+                                if (lane == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, word);  // before the stores
+                            }
+                            cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)ncol * N1;
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int m = 0; m < TE; ++m) st_slot<R>(dst + wt + m * PA::T, v[m]);
+                            asm volatile("" ::: "memory");  // the loads below stay behind the stores above
+                            pending = slot;
+                            issue_upper(i + 3);             // into the half of the strip just read
+                        }
+                        vm_wait<0>();
+                        if (lane == 0 && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((my_lines - 1) / a.ring + 1))
+                            __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
+                }
+#endif
+                issue_next(1);
+                for (uint32_t i = 0; i < my_lines; ++i) {
+                    const uint32_t slot = i % a.ring, round = i / a.ring;
+                    cx<R> v[TE];
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) v[m] = cur[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    dft8(v);
+#endif
+                    wstore0(v);
+                    wave_sync();
+                    auto announce = [&]() {
+                        // the LAST wave of the workgroup to see its stores of the pending line (i - 1) done announces the tile.
+                        // Counted per ring slot: the waves are not in step, but nobody arrives for line j + ring before line j
+                        // has been announced (its slot is not free before that)
+                        if (lane == 0 && pending != NONE && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((i - 1) / a.ring + 1))
+                            __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    };
+#if SPEC_TEAM_WA_ANN == 0
+                    // the previous line's stores have had this long: wait for them, not for the NLD loads behind them
+                    vm_wait<NLD>();
+                    announce();
+#endif
+                    wload(v);
+                    wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    wtw.pass1(v);
+#endif
+#if SPEC_TEAM_WA_ANN == 1
+                    vm_wait<NLD>();
+                    announce();
+#endif
+                    wstore1(v);
+                    wave_sync();
+                    wload(v);
+                    wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    wtw.pass2(v);
+#endif
+                    {   // inter-step twiddle W_N^(n2 k1), k1 = wt + T m: recurrence in fp64
+                        cx<double> w = ww0;
+#pragma unroll
+                        for (int m = 0; m < TE; ++m) {
+                            v[m] = cmul(v[m], w);
+                            w = cmul(w, wwstep);
+                        }
+                    }
+                    vm_wait<0>();  // line i + 1's rows, requested a whole line ago
+#if SPEC_TEAM_WA_ANN == 2
+                    announce();
+#endif
+                    if (HALF && follows(i + 1 < my_lines ? i + 1 : my_lines - 1)) {
+#pragma unroll
+                        for (int m = 0; m < NEWH; ++m) { cur[m] = cur[m + NEWH]; cur[m + NEWH] = mine[64 * (m + NEWH)]; }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < TE; ++m) cur[m] = mine[64 * m];
+                    }
+                    wave_sync();
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                    // is the slot free?  The poll was taken one line earlier (this wave's own word, parity i & 1; it landed
+                    // before the vm_wait<0> above); "not yet" is a blocking wait of this wave alone
+                    if (round != 0 && (pending == NONE || (int32_t)(pland[2u * wave + (i & 1u)] - NT * round) < 0) &&
+                        !wave_wait(ring + 32 * slot + 16, NT * round, sync)) return;
+#endif
+                    {
+                        const uint32_t word = __builtin_amdgcn_readfirstlane(pland_addr + 8u * wave + 4u * ((i + 1) & 1u));
+                        if (lane == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, word);  // before the stores
+                    }
+                    cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)ncol * N1;
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) st_slot<R>(dst + wt + m * PA::T, v[m]);
+                    asm volatile("" ::: "memory");  // the loads below stay behind the stores above
+                    pending = slot;
+                    issue_next(i + 2);
+                }
+                vm_wait<0>();
+                if (lane == 0 && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((my_lines - 1) / a.ring + 1))
+                    __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
         if constexpr (DIRECT && LD::PIPE) {
             if (win == nullptr) {
                 // ---- pipelined form: samples are cx<double> in memory, no window ----------------------------------
@@ -768,7 +1052,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 for (int m = 0; m < TE; ++m) st_slot<R>(dst + t1 + m * PA::T, v[m]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores are in L2
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot, APT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     } else {
@@ -959,7 +1243,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             PROF_PH(6);
         };
         (void)xstore0s; (void)rest_of_line_sx; (void)rest_of_line;
-        auto ready = [&](uint32_t j, uint32_t w) { return j < my_lines && (int32_t)(w - NT * (j / a.ring + 1)) >= 0; };
+        auto ready = [&](uint32_t j, uint32_t w) { return j < my_lines && (int32_t)(w - NT * APT * (j / a.ring + 1)) >= 0; };
         if constexpr (LD::PIPE) {
             // ---- pipelined form -----------------------------------------------------------------------------------------
             // Per line: [tile of line i + 1 into the strips, if the column side has it (poll taken one line earlier)]
@@ -978,7 +1262,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 if (tid == 0 && j < my_lines) glds4_sc1(ring + 32 * (j % a.ring), pland_addr);
             };
 #ifndef SPEC_ABL_TEAM_NOWAIT
-            if (!team_wait(ring, NT, sync, &s_flag)) return;
+            if (!team_wait(ring, NT * APT, sync, &s_flag)) return;
 #endif
             issue(0);
             issue_poll(1);
@@ -1051,7 +1335,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     PROF_T0();
                     PROF_INC(5);
 #ifndef SPEC_ABL_TEAM_NOWAIT
-                    if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
+                    if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * APT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
 #endif
                     PROF_ADD(3);
                     TRACE(5, i);
@@ -1077,7 +1361,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             };
             cx<R> nxt[TE];
 #ifndef SPEC_ABL_TEAM_NOWAIT
-            if (!team_wait(ring, NT, sync, &s_flag)) return;
+            if (!team_wait(ring, NT * APT, sync, &s_flag)) return;
 #endif
             load_tile(0, nxt);
             for (uint32_t i = 0; i < my_lines; ++i) {
@@ -1097,7 +1381,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 rest_of_line(v, line_of(i), [](auto) {});
                 if (!ahead && i + 1 < my_lines) {
 #ifndef SPEC_ABL_TEAM_NOWAIT
-                    if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
+                    if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * APT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
 #endif
                     load_tile(i + 1, nxt);
                 }
