@@ -27,7 +27,7 @@ def main():
         avail = cyc * 1024.0 / lines                         # SIMD-cycles per line
         valu, lds, vmem = (p[k] * 4.0 / lines for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"))
         wc = p["SQ_WAVE_CYCLES"]
-        rows.append((label, d["kernel"].split("(anonymous namespace)::")[-1][:46], d["timed_avg_ns"] / 1e6, ghz, avail, valu, lds, vmem,
+        rows.append((label, __import__("re").search(r"(\w+<[^>]*>)", d["kernel"]).group(1), d["timed_avg_ns"] / 1e6, ghz, avail, valu, lds, vmem,
                      p["SQ_INSTS_VALU"] / lines, p["SQ_INSTS_LDS"] / lines, p["SQ_INSTS_VMEM"] / lines,
                      p["SQ_ACTIVE_INST_VALU"] * 4.0 / p["SQ_INSTS_VALU"], p["SQ_ACTIVE_INST_LDS"] * 4.0 / p["SQ_INSTS_LDS"],
                      p["SQ_ACTIVE_INST_ANY"] / wc, p["SQ_WAIT_ANY"] / wc, p["SQ_WAIT_INST_ANY"] / wc, p["SQ_WAIT_INST_LDS"] / wc,
