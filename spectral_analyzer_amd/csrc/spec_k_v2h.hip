@@ -30,7 +30,7 @@ struct V2hArgs {
     uint32_t n_lines, hop, run;  // run: consecutive lines per workgroup
     const void *tw_half;   // v2f W_16384^m
     const void *tw_full;   // v2f W_32768^m
-    const void *win;       // float[32768] or nullptr
+    const void *win;       // non-null: Hann window (computed from the twiddles, the table is not read)
     float *out;
     int out_fmt;
 };
@@ -165,11 +165,12 @@ __global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
     const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw_half);
 
     fill_tables<L, 1>(tab, tw, t);
+    v2f *wtab = tab + p2_tab_entries<L>();  // W_64^m = W_N^(512 m), m < 32 (the Hann window's cosine, below)
+    if (HAS_WIN && t < 32) wtab[t] = static_cast<const v2f *>(a.tw_full)[512 * t];
     v2f twl[16];
 #pragma unroll
     for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (H - 1)];
     const v2f wt = static_cast<const v2f *>(a.tw_full)[t];  // W_N^t
-    const float *win = static_cast<const float *>(a.win);
     const bool db = a.out_fmt == OUT_DB20_F32;
 
     const uint32_t line0 = blockIdx.x * a.run;
@@ -202,13 +203,17 @@ __global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
         const int next_off = (int)((line + 1) * line_bytes);
         v2f v[E], dd[PARK_RAW ? 1 : E];
         (void)dd;
-        const float *wp = win;
-        if constexpr (HAS_WIN) asm volatile("" : "+s"(wp));  // keep the window loads inside the loop
         auto decode = [&](int m, v2f &lo, v2f &hi) {
             lo = RW::dec(BE ? RW::swap(rlo[m]) : rlo[m]);  // SMH:87-91 byte order
             hi = RW::dec(BE ? RW::swap(rhi[m]) : rhi[m]);
             if constexpr (HAS_WIN) {
-                const float w0 = wp[t + m * T], w1 = wp[H + t + m * T];
+                // Hann (the only window of the ABI): w[n] = 1/2 - 1/2 cos(2 pi n / N), and cos(2 pi n / N) = Re W_N^n =
+                // Re(W_N^t W_64^m) for n = t + 512 m -- from the twiddle the thread holds and W_64^m (a 32-entry LDS table), where the
+                // table cost two loads per sample from L2 for each half (0.32 of 8 TB/s against 0.43 without a window);
+                // n + H turns the cosine's sign.  (`win` only says that a window is wanted.)
+                const v2f cs = wtab[m];  // W_64^m from LDS (one broadcast read): as 64 literals the compiler pins them in registers
+                const float c = __builtin_fmaf(wt.x, cs.x, -(wt.y * cs.y));
+                const float w0 = __builtin_fmaf(-0.5f, c, 0.5f), w1 = __builtin_fmaf(0.5f, c, 0.5f);
                 lo *= v2f{w0, w0};
                 hi *= v2f{w1, w1};
             }
@@ -239,7 +244,6 @@ __global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
                 // decoded a second time from the parked raw registers; the empty asm keeps hipcc from re-using the first
                 // decode's floats instead (128 registers alive across the first transform)
                 asm volatile("" : "+v"(rlo[m]), "+v"(rhi[m]));
-                if constexpr (HAS_WIN && m == 0) asm volatile("" : "+s"(wp));  // ... nor its 64 window values
                 decode(m, lo, hi);
                 v[m] = v2h_twiddle<m>(lo - hi, wt);
             } else {
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
 }
 
 template <int KIND, bool HAS_WIN, bool BE, bool REUSE> hipError_t v2h_launch1(const V2hArgs &a, hipStream_t s) {
-    constexpr size_t lds = p2_lds_bytes<14>();
+    constexpr size_t lds = p2_lds_bytes<14>() + 32 * sizeof(v2f);  // + the W_64 table of the window
     auto kern = v2h_kernel<KIND, HAS_WIN, BE, REUSE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -80,3 +80,58 @@ def test_java_harness_calls_the_reference_entry_points():
         assert needle in src, needle
     assert src.count("{") == src.count("}") and src.count("(") == src.count(")")
     assert not re.search(r"\bnative\b", src.split("class SpectralServiceParityTest")[1])   # pure Java: runs against either class
+
+
+# ---- the JDSP probe (Welch PSD / down-converter semantics: source absent from the reference tree) ---------------------
+PROBE = os.path.join(ROOT, "integration", "java-test", "jdsp-probe")
+
+
+def test_jdsp_probe_inputs_are_what_the_exporter_writes(tmp_path):
+    import sys
+    sys.path.insert(0, GOLD)
+    try:
+        import export_jdsp_probe
+    finally:
+        sys.path.remove(GOLD)
+    export_jdsp_probe.export(str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == sorted(os.listdir(PROBE))
+    for name in os.listdir(PROBE):
+        with open(os.path.join(tmp_path, name), "rb") as a, open(os.path.join(PROBE, name), "rb") as b:
+            assert a.read() == b.read(), name
+    meta = json.load(open(os.path.join(PROBE, "probe.json")))
+    assert {s["name"]: s["nfft"] for s in meta["signals"]} == {"tone8192": 8192, "noise40000": 8192, "burst625": 625, "impulse8192": 8192}
+
+
+@pytest.mark.parametrize("truth", [
+    dict(window="hann", overlap="50 %", detrend="none", scaling="density", output="10 log10", order="fftshifted"),   # this build's default
+    dict(window="rect", overlap="0 %", detrend="none", scaling="density", output="linear", order="natural"),   # (rect + spectrum == rect + raw2)
+    dict(window="hamming", overlap="75 %", detrend="mean", scaling="raw", output="linear", order="fftshifted")])
+def test_fit_tool_recovers_a_known_convention(tmp_path, truth):
+    """tools/fit_jdsp.py against recordings SYNTHESISED under a known convention (no JDSP here): the convention comes out
+    first, with an error at rounding level, on every probe signal -- so a recording made by the real library will be named."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import fit_jdsp
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tools"))
+    meta = json.load(open(os.path.join(PROBE, "probe.json")))
+    for s in meta["signals"]:
+        x = fit_jdsp.load_signal(PROBE, s["name"])
+        psd = fit_jdsp.evaluate(truth, x, meta["fs"], s["nfft"])
+        freq = (np.arange(s["nfft"]) - s["nfft"] // 2) * meta["fs"] / s["nfft"]
+        np.concatenate([freq, psd]).astype("<f8").tofile(os.path.join(tmp_path, s["name"] + ".psd.f64"))
+    best, per_signal = fit_jdsp.fit(str(tmp_path), PROBE, verbose=False)
+    assert json.loads(best[0][1]) == truth and best[0][0] <= 1e-9
+    assert best[1][0] > 1e-6                                  # ... and nothing else fits all four signals
+    assert set(per_signal) == {s["name"] for s in meta["signals"]}
+
+
+def test_jdsp_probe_source_makes_the_reference_calls():
+    src = open(os.path.join(ROOT, "integration", "java-test", "JdspSemanticsProbe.java")).read()
+    for needle in ("import net.kcundercover.jdsp.signal.PowerSpectralDensity;", "import net.kcundercover.jdsp.signal.Resampler;",
+                   "PowerSpectralDensity.calculatePsdWelch(new double[][] {re, im}, fs, nfft)",
+                   "Resampler.downConvertPolyphase(re, im, freqOff, 1.0, down)", "new Resampler(1, down).downConvert(re, im, freqOff, 1.0)",
+                   "observed.json"):
+        assert needle in src, needle
+    assert src.count("{") == src.count("}") and src.count("(") == src.count(")")
