@@ -101,7 +101,11 @@ spec_status spec_create(int device, void *hip_stream, uint32_t flags, spec_ctx *
 void spec_destroy(spec_ctx *ctx);
 
 /* Text of the last failure on `ctx` (or of the last failed spec_create when ctx
- * is NULL).  Never NULL. */
+ * is NULL).  Never NULL.  On a context shared by threads a thread sees its OWN last failure on that context if it
+ * has one (whatever other threads did since), otherwise a copy of the context's last failure.  The pointer belongs to
+ * the calling thread and stays valid until that thread's next call that fails on this context (own failure) or its
+ * next spec_last_error() about a context it has no failure of its own on (copy); asking about one context never
+ * changes what was returned for another. */
 const char *spec_last_error(const spec_ctx *ctx);
 const char *spec_status_string(spec_status st);
 

@@ -113,6 +113,7 @@ struct spec_recording {
 static thread_local std::string g_create_err;
 // the calling thread's own last failure (a context shared by threads has one `err` for all of them)
 static thread_local std::string t_err;
+static thread_local std::string t_other;  // spec_last_error: this thread's copy of ANOTHER thread's failure text
 static thread_local const spec_ctx *t_err_ctx = nullptr;
 static thread_local uint64_t t_err_gen = 0;
 static std::atomic<uint64_t> g_ctx_gen{0};
@@ -216,12 +217,12 @@ const char *spec_last_error(const spec_ctx *ctx) {
     if (t_err_ctx == ctx && t_err_gen == ctx->gen) return t_err.c_str();
     // another thread's failure: copied under the context's lock (that thread may be inside fail() right now), and the
     // pointer handed out is this thread's own copy
+    // pointer handed out is a copy of this thread's own -- a SECOND one: asking about context B must neither overwrite
+    // this thread's recorded failure on context A nor invalidate the text an earlier spec_last_error(A) returned
     spec_ctx *c = const_cast<spec_ctx *>(ctx);
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    t_err = c->err;
-    t_err_ctx = ctx;
-    t_err_gen = ctx->gen;
-    return t_err.c_str();
+    t_other = c->err;
+    return t_other.c_str();
 }
 
 spec_dtype spec_dtype_from_sigmf(const char *s) {
@@ -332,6 +333,17 @@ spec_status spec_sync(spec_ctx *c) {
     if (!c) return SPEC_EINVAL;
     Enter g(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the host is synchronised anyway: did the last default-mode large-N call's persistent launch give up?  (Otherwise the
+    // word is looked at lazily, at the next large-N call that finds the stream idle -- a host that queues such calls back
+    // to back and only ever calls spec_sync would never learn.)
+    if (c->team_check_pending && c->team_sync) {
+        uint32_t aborted = 0;
+        if (hipMemcpyAsync(&aborted, static_cast<uint32_t *>(c->team_sync) + large_team_abort_word(), 4, hipMemcpyDeviceToHost,
+                           c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) {
+            c->team_check_pending = false;
+            if (aborted) c->team_disabled = true;
+        }
+    }
     return SPEC_OK;
 }
 

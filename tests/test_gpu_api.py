@@ -744,6 +744,30 @@ def test_last_error_is_not_inherited_from_a_destroyed_context(oracle):
             b.close()
 
 
+def test_last_error_of_one_context_does_not_disturb_another(oracle):
+    """Round-3 advisor: asking about context B used to overwrite this thread's recorded failure on context A (one
+    thread-local cache) and to invalidate the text an earlier spec_last_error(A) had returned."""
+    import threading
+    import torch
+    iq = oracle.synth_iq("cf32_le", 1, 0, 4096)
+    a = sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream)
+    b = sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream)
+    try:
+        with pytest.raises(ValueError, match="power of two"):
+            a.compute_waterfall(iq, 0, 1000, "cf32_le", 1)                  # this thread's failure on A
+        def other():                                                        # another thread fails on B
+            with pytest.raises(ValueError, match="hop"):
+                b.compute_waterfall(iq, 0, 1024, "cf32_le", 1, hop=0)
+        t = threading.Thread(target=other); t.start(); t.join()
+        text_a = a._lib.spec_last_error(a._ctx)
+        assert b"power of two" in text_a
+        assert b"hop" in b._lib.spec_last_error(b._ctx)                     # a COPY of the other thread's text ...
+        assert a._lib.spec_last_error(a._ctx) == text_a and b"power of two" in a._lib.spec_last_error(a._ctx)   # ... and A's is intact
+    finally:
+        a.close()
+        b.close()
+
+
 @pytest.mark.parametrize("datatype,nfft,hop,n_seg,n_psd", [("cf32_le", 1024, 512, 6, 7), ("ci16_le", 4096, 1024, 9, 600),
                                                            ("cf64_le", 2048, 2048, 3, 5), ("cu8", 1000, 300, 4, 2),
                                                            ("cf32_le", 256, 64, 33, 1)])
