@@ -145,6 +145,10 @@ void *spec_stream(const spec_ctx *ctx);
  *                     per line -- a radix-2 step in registers, then two 16384-point transforms through the same LDS buffer,
  *                     nothing handed over between workgroups (cf32 0.45, ci16 0.43 of 8 TB/s against 0.26 / 0.10 for the
  *                     four-step team kernel); 0 = the four-step paths of "large_team"
+ *   "mid_single" = 2 | 1 | 0   16384-point fp32 lines through the same half-line kernel (256-thread workgroups, two per CU):
+ *                     2 (default) = where it was measured faster than the family's kernel (everything but cf32 / ci16 at 75 %
+ *                     overlap and cf32 at 50 % overlap without a window, where the family keeps the overlap in registers),
+ *                     1 = always, 0 = never
  *   "multi_verify" = 0 | 1   spec_waterfall_multi / spec_welch_psd_multi with a device-resident result: 1 = every piece a
  *                     peer context sends is checksummed on its own device before it leaves and again where it landed on
  *                     the consumer's device; a difference is SPEC_EDEVICE and the message names piece, devices and the path

@@ -84,10 +84,10 @@ hipError_t launch_v3d_spectro(const WfArgs &w, int log2n, uint32_t run, hipStrea
 // 16-byte-per-lane pieces through its own LDS region; `first` = address of the first line's first byte (alignment)
 bool v2n_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop, const void *first);
 hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t s);
-// 32768-point fp32 lines in one workgroup (spec_k_v2h.hip): w.tw = v2f W_32768 table, tw_half = v2f W_16384 table, w.win =
-// float[32768] or nullptr; `run` consecutive lines per workgroup
+// 32768- (and, as an option, 16384-) point fp32 lines in one workgroup (spec_k_v2h.hip): w.tw = v2f W_N table, tw_half = v2f
+// W_(N/2) table, w.win = non-null for the Hann window; `run` consecutive lines per workgroup
 bool v2h_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop);
-hipError_t launch_v2h_spectro(const WfArgs &w, const void *tw_half, uint32_t run, hipStream_t s);
+hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, uint32_t run, hipStream_t s);
 bool v2_sel_applicable(int log2n, int kind, int be, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v2_spectro_sel(const WfArgs &w, int log2n, uint32_t run, const int32_t *sel, uint32_t out_stride,
                                  hipStream_t s);

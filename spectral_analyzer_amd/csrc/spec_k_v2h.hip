@@ -147,9 +147,10 @@ template <bool BOUNDED, int E> __device__ __forceinline__ void v2h_epilogue(cons
 #endif
 
 // REUSE: hop == N/2 and a 2- / 4-byte format -- the raw upper half stays in registers as the next line's lower half
-template <int KIND, bool HAS_WIN, bool BE, bool REUSE>
-__global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
-    constexpr int L = 14;
+// L: log2 of the HALF line (14: 32768-point lines, one 512-thread workgroup per CU; 13: 16384-point lines, 256-thread
+// workgroups, two per CU -- two independent barrier domains on every SIMD)
+template <int L, int KIND, bool HAS_WIN, bool BE, bool REUSE>
+__global__ __launch_bounds__(Plan2<L>::T, 2) void v2h_kernel(const V2hArgs a) {
     using PL = Plan2<L>;
     using RW = Raw2<KIND>;
     using raw_t = typename RW::type;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
     constexpr bool PARK_RAW = KIND != K_CF32;  // park the raw samples (E + E registers) instead of the decoded difference
     constexpr int PF = V2H_PF;
     static_assert(!REUSE || PARK_RAW, "register reuse needs the raw halves parked");
-    static_assert(T == 512 && E == 32, "one 512-thread workgroup, 32 points per thread and half");
+    static_assert(E == 32 && N / T == 64, "32 points per thread and half: n = t + T m, W_N^(T m) = W_64^m");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     v2f *lds = reinterpret_cast<v2f *>(smem);
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
 
     fill_tables<L, 1>(tab, tw, t);
     v2f *wtab = tab + p2_tab_entries<L>();  // W_64^m = W_N^(512 m), m < 32 (the Hann window's cosine, below)
-    if (HAS_WIN && t < 32) wtab[t] = static_cast<const v2f *>(a.tw_full)[512 * t];
+    if (HAS_WIN && t < 32) wtab[t] = static_cast<const v2f *>(a.tw_full)[T * t];
     v2f twl[16];
 #pragma unroll
     for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (H - 1)];
@@ -282,44 +283,48 @@ __global__ __launch_bounds__(512, 2) void v2h_kernel(const V2hArgs a) {
     }
 }
 
-template <int KIND, bool HAS_WIN, bool BE, bool REUSE> hipError_t v2h_launch1(const V2hArgs &a, hipStream_t s) {
-    constexpr size_t lds = p2_lds_bytes<14>() + 32 * sizeof(v2f);  // + the W_64 table of the window
-    auto kern = v2h_kernel<KIND, HAS_WIN, BE, REUSE>;
+template <int L, int KIND, bool HAS_WIN, bool BE, bool REUSE> hipError_t v2h_launch1(const V2hArgs &a, hipStream_t s) {
+    constexpr size_t lds = p2_lds_bytes<L>() + 32 * sizeof(v2f);  // + the W_64 table of the window
+    auto kern = v2h_kernel<L, KIND, HAS_WIN, BE, REUSE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((a.n_lines + a.run - 1) / a.run), dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.n_lines + a.run - 1) / a.run), dim3(Plan2<L>::T), lds, s, a);
     return hipGetLastError();
 }
 
-template <int KIND, bool BE> hipError_t v2h_launch_kind(const V2hArgs &a, hipStream_t s) {
+template <int L, int KIND, bool BE> hipError_t v2h_launch_kind(const V2hArgs &a, hipStream_t s) {
     const bool win = a.win != nullptr;
     if constexpr (KIND != K_CF32) {
-        if (a.hop == 16384u) return win ? v2h_launch1<KIND, true, BE, true>(a, s) : v2h_launch1<KIND, false, BE, true>(a, s);
+        if (a.hop == (uint32_t)Plan2<L>::N) return win ? v2h_launch1<L, KIND, true, BE, true>(a, s) : v2h_launch1<L, KIND, false, BE, true>(a, s);
     }
-    return win ? v2h_launch1<KIND, true, BE, false>(a, s) : v2h_launch1<KIND, false, BE, false>(a, s);
+    return win ? v2h_launch1<L, KIND, true, BE, false>(a, s) : v2h_launch1<L, KIND, false, BE, false>(a, s);
+}
+
+template <int L> hipError_t v2h_launch_l(const V2hArgs &a, int kind, int be, hipStream_t s) {
+    switch (kind) {
+    case K_CF32: return be ? v2h_launch_kind<L, K_CF32, true>(a, s) : v2h_launch_kind<L, K_CF32, false>(a, s);
+    case K_CI16: return be ? v2h_launch_kind<L, K_CI16, true>(a, s) : v2h_launch_kind<L, K_CI16, false>(a, s);
+    case K_CU8: return v2h_launch_kind<L, K_CU8, false>(a, s);
+    case K_CI8: return v2h_launch_kind<L, K_CI8, false>(a, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
 
 bool v2h_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop) {
-    if (log2n != 15) return false;
+    if (log2n != 15 && log2n != 14) return false;
     if (kind != K_CF32 && kind != K_CI16 && kind != K_CU8 && kind != K_CI8) return false;
     if (out_fmt != OUT_DB20_F32 && out_fmt != OUT_POW_F32) return false;
-    return n_lines > 0 && n_lines < (1ull << 31) && hop <= (8u << 15);  // a workgroup's span stays far below 4 GiB
+    return n_lines > 0 && n_lines < (1ull << 31) && hop <= (8u << log2n);  // a workgroup's span stays far below 4 GiB
 }
 
-hipError_t launch_v2h_spectro(const WfArgs &w, const void *tw_half, uint32_t run, hipStream_t s) {
+hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, uint32_t run, hipStream_t s) {
     V2hArgs a{};
     a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.run = run;
     a.tw_half = tw_half; a.tw_full = w.tw; a.win = w.win;
     a.out = static_cast<float *>(w.out); a.out_fmt = w.out_fmt;
-    switch (w.kind) {
-    case K_CF32: return w.be ? v2h_launch_kind<K_CF32, true>(a, s) : v2h_launch_kind<K_CF32, false>(a, s);
-    case K_CI16: return w.be ? v2h_launch_kind<K_CI16, true>(a, s) : v2h_launch_kind<K_CI16, false>(a, s);
-    case K_CU8: return v2h_launch_kind<K_CU8, false>(a, s);
-    case K_CI8: return v2h_launch_kind<K_CI8, false>(a, s);
-    default: return hipErrorInvalidValue;
-    }
+    return log2n == 15 ? v2h_launch_l<14>(a, w.kind, w.be, s) : v2h_launch_l<13>(a, w.kind, w.be, s);
 }
 
 }  // namespace specgpu

@@ -131,7 +131,8 @@ def test_team_and_two_launch_paths_agree(svc, oracle):
 
 @pytest.mark.parametrize("datatype,nfft,hop,n_lines,window,fmt", [
     ("cf64_le", 65536, 32768, 300, sa.WIN_RECT, sa.OUT_DB20_F64), ("cf64_be", 16384, 5000, 70, sa.WIN_HANN, sa.OUT_POW_F64),
-    ("cf32_le", 65536, 32768, 257, sa.WIN_RECT, sa.OUT_DB20_F32), ("ci16_le", 32768, 32768, 64, sa.WIN_HANN, sa.OUT_POW_F32)])
+    ("cf32_le", 65536, 32768, 257, sa.WIN_RECT, sa.OUT_DB20_F32), ("ci16_le", 32768, 32768, 64, sa.WIN_HANN, sa.OUT_POW_F32),
+    ("cf64_le", 32768, 16384, 70, sa.WIN_RECT, sa.OUT_DB20_F64)])   # large_solo<double, 7, 8> (round-3 advisor)
 def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nfft, hop, n_lines, window, fmt):
     """Behind the persistent team kernel sits ONE guarded launch (large_solo_kernel: every workgroup owns whole lines
     and an intermediate of its own, nothing waits for another workgroup) instead of round 2's launch pair per 1 GiB
@@ -158,7 +159,8 @@ def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nf
 def test_a_context_stops_trying_the_team_kernel_after_one_abort(oracle):
     """The default mode never waits for the team kernel's abort word (the call stays asynchronous; the guarded fall-back
     repairs the result).  The context looks at the PREVIOUS call's word at its next large-N call, once its stream is
-    idle, and after one abort takes the two-launch path instead of spinning to the 2 s limit in every call; setting the
+    idle -- or in spec_sync, where the host waits anyway -- and after one abort takes the two-launch path instead of spinning
+    to the 2 s limit in every call; setting the
     "large_team" knob re-arms the team kernel.  The abort is simulated ("large_team_fake_abort")."""
     import torch
     s = sa.SpectralService(0, stream=torch.cuda.Stream().cuda_stream)
@@ -177,10 +179,18 @@ def test_a_context_stops_trying_the_team_kernel_after_one_abort(oracle):
         assert same(run(), two) and s.get_option("large_team_disabled") == 0    # default mode: the team kernel, no complaint
         assert same(run(), two) and s.get_option("large_team_disabled") == 0
         s.set_option("large_team_fake_abort", 1)
-        assert same(run(), two)                            # "timed out": the guarded fall-back wrote the lines
-        assert s.get_option("large_team_disabled") == 0    # ... and nobody has looked at the abort word yet
-        assert same(run(), two)                            # looked at here, at the next call's entry
+        o = s.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=sa.OUT_POW_F64)   # "timed out": asynchronous, ...
+        assert s.get_option("large_team_disabled") == 0    # ... nobody has looked at the abort word yet
+        s.synchronize()                                    # spec_sync does (round 4: wherever the host synchronises anyway)
+        assert same(o.clone(), two)                        # the guarded fall-back wrote the lines
         assert s.get_option("large_team_disabled") == 1    # two-launch path from now on
+        s.set_option("large_team", 1)                      # re-armed; this time the word is found at the NEXT call's entry:
+        s.set_option("large_team_fake_abort", 1)
+        o = s.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=sa.OUT_POW_F64)
+        torch.cuda.synchronize()                           # (the device is idle, the context has not been asked)
+        assert s.get_option("large_team_disabled") == 0
+        assert same(run(), two)                            # looked at here, at the next large-N call's entry
+        assert s.get_option("large_team_disabled") == 1
         assert same(run(), two) and s.get_option("large_team_disabled") == 1
         s.set_option("large_team", 1)                      # the knob re-arms the persistent launch
         assert s.get_option("large_team_disabled") == 0 and same(run(), two)

@@ -104,3 +104,29 @@ def test_every_value_at_full_size(svc):
         svc.set_option("large_team", 1)
         del iq
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be", "ci16_le", "cu8", "ci8"])
+@pytest.mark.parametrize("hop,window", [(8192, sa.WIN_RECT), (16384, sa.WIN_HANN), (4096, sa.WIN_RECT), (5000, sa.WIN_HANN)])
+def test_half_line_kernel_at_16384_points(svc, oracle, datatype, hop, window):
+    """The same kernel one size down (256-thread workgroups, two per CU; "mid_single" = 1 forces it, the default takes it
+    where it was measured faster than the family's 16384-point kernel): against the oracle, and the family's kernel
+    ("mid_single" = 0) agrees to fp32 rounding."""
+    import torch
+    nfft, n_lines = 16384, 10
+    iq = oracle.synth_iq(datatype, seed=hop + window + 1, first_sample=2, n_samples=(n_lines - 1) * hop + nfft)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines + 1, window=window)
+    d = torch.from_numpy(iq).cuda()
+    try:
+        out = {}
+        for mode in (1, 0, 2):
+            svc.set_option("mid_single", mode)
+            got = svc.compute_waterfall(d, 0, nfft, datatype, n_lines + 1, hop=hop, window=window)
+            torch.cuda.synchronize()
+            out[mode] = got.cpu().numpy()
+            assert np.all(out[mode][n_lines:] == -150.0)
+            check_fp32(out[mode][:n_lines], ref[:n_lines], nfft)
+        assert not np.array_equal(out[1], out[0])                       # two different kernels
+        assert np.array_equal(out[2], out[1]) or np.array_equal(out[2], out[0])
+    finally:
+        svc.set_option("mid_single", 2)
