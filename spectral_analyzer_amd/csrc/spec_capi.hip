@@ -631,9 +631,10 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "large-N team query: %s", hipGetErrorString(e));
             if ((st = grow(c, &c->team_scratch, &c->team_scratch_bytes, (size_t)(teams_max ? teams_max : 1) * ring * per_line)) != SPEC_OK) return st;
             if ((st = grow(c, &c->team_sync, &c->team_sync_bytes, large_team_sync_bytes())) != SPEC_OK) return st;
-            // the fall-back's intermediates: one line per workgroup, one workgroup per CU (256 MiB for 65536-point fp64
-            // lines; round 2 kept a 1 GiB chunk scratch for the same purpose)
-            const uint32_t solo_grid = (uint32_t)c->n_cu;
+            // the fall-back's intermediates: one line per workgroup (round 2 kept a 1 GiB chunk scratch for the same purpose)
+            // (a quarter of the CUs: the fall-back almost never runs, and its scratch is allocated with the first large-N call
+            // whether it does or not -- 64 MiB instead of 256 MiB for 65536-point fp64 lines)
+            const uint32_t solo_grid = (uint32_t)(c->n_cu >= 4 ? c->n_cu / 4 : 1);
             if (c->opt_large_team != 2 && (st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)solo_grid * per_line)) != SPEC_OK) return st;
             for (uint64_t done = 0; done < n_lines;) {
                 const uint64_t nl = n_lines - done < 0x40000000ull ? n_lines - done : 0x40000000ull;  // 32-bit line index
