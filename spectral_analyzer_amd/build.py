@@ -73,6 +73,10 @@ VARIANTS = {
     "tWA2": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2"], ["spec_k_team.hip"]),
     "tWA1a": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=1", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
     "tWA2a": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
+    "tWAca": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
+    "tWAcb": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT"], ["spec_k_team.hip"]),
+    "tWAsa": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
+    "tWAc": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED"], ["spec_k_team.hip"]),
     "tOLDa": (["-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
     "v2hpf0": (["-DV2H_PF=0"], ["spec_k_v2h.hip"]),
     "v2hpf8": (["-DV2H_PF=8"], ["spec_k_v2h.hip"]),

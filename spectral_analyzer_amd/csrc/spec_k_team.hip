@@ -663,7 +663,12 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #pragma unroll
                     for (int m = 0; m < TE; ++m) x[m] = colbuf[pad8((int)wt + m * PA::T)];
                 };
+#ifdef SPEC_ABL_WA_COALESCED  // ablation (results WRONG by construction): the same request volume as 256-byte rows -- 16 neighbouring
+                                   // lanes = the workgroup's 16 columns of one row -- to price the 32-byte pieces of the real thing
+                const uint32_t dk = 4u * wave + lane / 16u, dcol = c0 + lane % 16u;
+#else
                 const uint32_t dk = lane / CPW, dcol = c0 + CPW * wave + lane % CPW;  // request role: row dk (+ T m) of column dcol
+#endif
                 constexpr int NLD = HALF ? NEWH : TE;
                 auto issue_rows = [&](uint32_t line, auto first_tag, auto end_tag) {
                     constexpr int FIRST = decltype(first_tag)::value, END = decltype(end_tag)::value;
