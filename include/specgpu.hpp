@@ -23,6 +23,14 @@ public:
     SpectralService(const SpectralService &) = delete;
     SpectralService &operator=(const SpectralService &) = delete;
 
+    // tuning / testing knobs and read-only state of specgpu.h's spec_set_option / spec_get_option ("multi_verify", ...)
+    void setOption(const std::string &key, int64_t value) { check(spec_set_option(ctx_, key.c_str(), value), ctx_); }
+    int64_t getOption(const std::string &key) const {
+        int64_t v = 0;
+        check(spec_get_option(ctx_, key.c_str(), &v), ctx_);
+        return v;
+    }
+
     // SpectralService.java:33-85; `big_endian` is the buffer's byte order (SigMfHelper.java:87-91)
     std::vector<double> computeMagnitudes(const void *buffer, uint64_t capacity, int64_t startByte, uint32_t nfft,
                                           const std::string &datatype, bool big_endian) const {

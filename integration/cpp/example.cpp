@@ -27,6 +27,10 @@ int main() {
         catch (const std::out_of_range &) {}
         try { svc.computeMagnitudes(iq.data(), iq.size() * 2, 0, 1000, "ci16_le", false); ok = false; }
         catch (const std::invalid_argument &) {}
+        svc.setOption("multi_verify", 1);                   // knobs of specgpu.h through the mirror
+        ok = ok && svc.getOption("multi_verify") == 1;
+        try { svc.getOption("no_such_knob"); ok = false; }
+        catch (const std::invalid_argument &) {}
         std::puts(ok ? "example ok" : "example FAILED");
         return ok ? 0 : 1;
     } catch (const std::exception &e) {

@@ -243,6 +243,24 @@ public class SpectralService implements AutoCloseable {
         nativeDestroy(handle);
     }
 
+    /**
+     * A tuning / testing knob of the native library (include/specgpu.h, spec_set_option): e.g.
+     * {@code setOption("multi_verify", 1)} on {@code services[0]} makes {@link #computeWaterfallMulti} checksum every piece a
+     * peer GPU sends before it leaves and where it landed.
+     *
+     * @throws IllegalArgumentException unknown key
+     */
+    public void setOption(String key, long value) {
+        nativeSetOption(handle, key, value);
+    }
+
+    /** Current value of a knob, or of a read-only state such as {@code "multi_peer_access"} / {@code "multi_verified"}. */
+    public long getOption(String key) {
+        return nativeGetOption(handle, key);
+    }
+
+    private static native void nativeSetOption(long handle, String key, long value);
+    private static native long nativeGetOption(long handle, String key);
     private static native long nativeCreate(int device, int flags);
     private static native void nativeDestroy(long handle);
     private static native void nativeComputeMagnitudes(long handle, ByteBuffer buffer, int startByte, int nfft,

@@ -46,6 +46,31 @@ JNIEXPORT jlong JNICALL JNI_FN(nativeCreate)(JNIEnv *env, jclass k, jint device,
     return (jlong)(intptr_t)ctx;
 }
 
+/* tuning / testing knobs of spec_set_option / spec_get_option (include/specgpu.h), e.g. "multi_verify" */
+JNIEXPORT void JNICALL JNI_FN(nativeSetOption)(JNIEnv *env, jclass k, jlong h, jstring key, jlong value) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    if (!ctx || !key) { throw_shim(env, "setOption: closed service or null key"); return; }
+    const char *s = (*env)->GetStringUTFChars(env, key, NULL);
+    if (!s) return;  /* OutOfMemoryError is pending */
+    const spec_status st = spec_set_option(ctx, s, (int64_t)value);
+    (*env)->ReleaseStringUTFChars(env, key, s);
+    if (st != SPEC_OK) throw_status(env, ctx, st);
+}
+
+JNIEXPORT jlong JNICALL JNI_FN(nativeGetOption)(JNIEnv *env, jclass k, jlong h, jstring key) {
+    (void)k;
+    spec_ctx *ctx = (spec_ctx *)(intptr_t)h;
+    if (!ctx || !key) { throw_shim(env, "getOption: closed service or null key"); return 0; }
+    const char *s = (*env)->GetStringUTFChars(env, key, NULL);
+    if (!s) return 0;
+    int64_t v = 0;
+    const spec_status st = spec_get_option(ctx, s, &v);
+    (*env)->ReleaseStringUTFChars(env, key, s);
+    if (st != SPEC_OK) { throw_status(env, ctx, st); return 0; }
+    return (jlong)v;
+}
+
 JNIEXPORT void JNICALL JNI_FN(nativeDestroy)(JNIEnv *env, jclass k, jlong h) {
     (void)env; (void)k;
     spec_destroy((spec_ctx *)(intptr_t)h);

@@ -27,6 +27,8 @@ void SS(nativeDestroy)(JNIEnv *, jclass, jlong);
 void SS(nativeComputeMagnitudes)(JNIEnv *, jclass, jlong, jobject, jint, jint, jstring, jboolean, jdoubleArray);
 void SS(nativeWaterfall)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, jint, jlong, jint, jdouble, jfloatArray);
 void SS(nativeWaterfallMulti)(JNIEnv *, jclass, jlongArray, jobject, jlong, jint, jint, jint, jlong, jint, jdouble, jfloatArray);
+void SS(nativeSetOption)(JNIEnv *, jclass, jlong, jstring, jlong);
+jlong SS(nativeGetOption)(JNIEnv *, jclass, jlong, jstring);
 void SS(nativeWelch)(JNIEnv *, jclass, jlong, jobject, jlong, jint, jint, jint, jint, jint, jint, jdouble, jboolean,
                      jdoubleArray, jfloatArray);
 void SS(nativeWelchMulti)(JNIEnv *, jclass, jlongArray, jobject, jlong, jlong, jint, jint, jint, jint, jint, jint, jint, jdouble,
@@ -203,6 +205,17 @@ int main(void) {
         CHECK(memcmp(tile, tile_ref, (size_t)LINES * NFFT * 4) == 0, "computeWaterfallMulti differs from the single-context tile");
         SS(nativeWaterfallMulti)(env, NULL, &a_hs, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile_short);
         expect_throw("java/lang/IllegalArgumentException", "shorter than nLines", "short tile (multi)");
+        {   /* knobs through the shim: set, read back, unknown key */
+            fake_obj k_mv = mk_string("multi_verify"), k_bad = mk_string("no_such_knob");
+            SS(nativeSetOption)(env, NULL, h, &k_mv, 1);
+            expect_clean("setOption");
+            CHECK(SS(nativeGetOption)(env, NULL, h, &k_mv) == 1, "getOption(multi_verify) after setOption");
+            expect_clean("getOption");
+            SS(nativeSetOption)(env, NULL, h, &k_mv, 0);
+            expect_clean("setOption back");
+            (void)SS(nativeGetOption)(env, NULL, h, &k_bad);
+            expect_throw("java/lang/IllegalArgumentException", "unknown key", "unknown option key");
+        }
         jlong twice[2] = {h, h};
         fake_obj a_twice = mk_array(twice, 2, 8);
         SS(nativeWaterfallMulti)(env, NULL, &a_twice, &buf, start, SPEC_DT_CI16_LE, NFFT, NFFT, LINES, SPEC_WIN_RECT, -150.0, &a_tile);

@@ -35,7 +35,8 @@ def test_shim_exports_the_mangled_names(harness):
     shim = os.path.join(os.path.dirname(harness), "libspecgpu_jni.so")
     syms = subprocess.run(["nm", "-D", "--defined-only", shim], capture_output=True, text=True, check=True).stdout
     for n in ("SpectralService_nativeComputeMagnitudes", "SpectralService_nativeWaterfall",
-              "SpectralService_nativeWelchPlanar", "ExtractDownConvertService_nativeExtractAndDownConvert"):
+              "SpectralService_nativeWelchPlanar", "SpectralService_nativeSetOption", "SpectralService_nativeGetOption",
+              "ExtractDownConvertService_nativeExtractAndDownConvert"):
         assert "Java_net_kcundercover_spectral_1analyzer_services_" + n in syms
 
 
