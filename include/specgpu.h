@@ -141,10 +141,11 @@ void *spec_stream(const spec_ctx *ctx);
  *                     CU, one of either role on every CU) and 1024 (two 512-thread workgroups per CU at 128 registers) were
  *                     measured slower and live in the variant library lib/libspecgpu_teamvar.so
  *                     (python -m spectral_analyzer_amd.build --variant teamvar); the product returns SPEC_EUNSUPPORTED
- *   "large_single" = 1 | 0   32768-point fp32 lines (the default dispatch, "large_team" = 1): 1 (default) = ONE workgroup
- *                     per line -- a radix-2 step in registers, then two 16384-point transforms through the same LDS buffer,
- *                     nothing handed over between workgroups (cf32 0.45, ci16 0.43 of 8 TB/s against 0.26 / 0.10 for the
- *                     four-step team kernel); 0 = the four-step paths of "large_team"
+ *   "large_single" = 1 | 0   32768-point fp32 and 16384-point fp64 lines (256 KiB; the default dispatch, "large_team" = 1):
+ *                     1 (default) = ONE workgroup per line -- a radix-2 step in registers, then two half-size transforms
+ *                     through the same LDS buffer, nothing handed over between workgroups (fp32: cf32 0.45, ci16 0.43 of
+ *                     8 TB/s against 0.26 / 0.10 for the four-step team kernel; fp64: cf64 0.37 against 0.32, cf32 -> f64
+ *                     0.30 against 0.14); 0 = the four-step paths of "large_team"
  *   "mid_single" = 2 | 1 | 0   16384-point fp32 lines through the same half-line kernel (256-thread workgroups, two per CU):
  *                     2 (default) = where it was measured faster than the family's kernel (everything but cf32 / ci16 at 75 %
  *                     overlap and cf32 at 50 % overlap without a window, where the family keeps the overlap in registers),

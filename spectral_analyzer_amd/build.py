@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libspecgpu.so")
-SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_large.hip", "spec_k_team.hip", "spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2n.hip", "spec_k_v2h.hip", "spec_k_v3d.hip", "spec_misc.hip", "spec_burst.hip"]
+SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_large.hip", "spec_k_team.hip", "spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2n.hip", "spec_k_v2h.hip", "spec_k_v3d.hip", "spec_k_v3h.hip", "spec_misc.hip", "spec_burst.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
@@ -81,6 +81,8 @@ VARIANTS = {
     "v2hpf0": (["-DV2H_PF=0"], ["spec_k_v2h.hip"]),
     "v2hpf8": (["-DV2H_PF=8"], ["spec_k_v2h.hip"]),
     "v2hpf20": (["-DV2H_PF=20"], ["spec_k_v2h.hip"]),
+    "v3he48": (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"]),
+    "v3he64": (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"]),
 }
 
 

@@ -596,6 +596,28 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         }
         return SPEC_OK;
     }
+    if (large && f64 && c->opt_large_single && c->opt_large_team == 1 && !d_sel && v3h_applicable(log2n, a.kind, n_lines, hop)) {
+        // 16384-point fp64 lines (256 KiB, as the 32768-point fp32 line above): one workgroup per line, a radix-2 step in
+        // registers and two 8192-point transforms of the fp64 family (spec_k_v3h.hip)
+        const void *tw_half = nullptr;
+        if ((st = get_twiddles(c, log2n - 1, true, &tw_half)) != SPEC_OK) return st;
+        uint64_t done = 0;
+        while (done < n_lines) {
+            const uint64_t rem = n_lines - done;
+            const uint64_t wgs_wanted = (uint64_t)c->n_cu * 2;
+            uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg : (rem + wgs_wanted - 1) / wgs_wanted;
+            if (run < 1) run = 1;
+            if (run > 32) run = 32;
+            while (run > 1 && run * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;  // 32-bit offsets in a span
+            a.n_lines = rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_v3h_spectro(a, tw_half, (uint32_t)run, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "16384-point fp64 launch: %s", hipGetErrorString(e));
+            done += a.n_lines;
+        }
+        return SPEC_OK;
+    }
     if (large) {
         const void *tw1 = nullptr, *tw2 = nullptr;
         if ((st = get_twiddles(c, l1, f64, &tw1)) != SPEC_OK) return st;

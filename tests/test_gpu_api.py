@@ -660,7 +660,8 @@ def test_waterfall_render_fused_device_resident(svc, oracle):
 # ---- spec_waterfall_multi: one waterfall over several contexts (SURVEY 8e at the C ABI) ------------------------
 @pytest.mark.parametrize("datatype,nfft,hop,n_lines,fmt", [("cf32_le", 4096, 2048, 1001, sa.OUT_DB20_F32),
                                                            ("ci16_le", 1024, 1024, 77, sa.OUT_DB20_F32),
-                                                           ("cf64_le", 16384, 8192, 60, sa.OUT_DB20_F64),   # < 64 lines: the two-launch four-step path in every context (three persistent team kernels cannot share ONE device)
+                                                           ("cf64_le", 16384, 8192, 60, sa.OUT_DB20_F64),   # the single-workgroup fp64 kernel
+                                                           ("cf64_le", 32768, 16384, 40, sa.OUT_DB20_F64),  # < 64 lines: the two-launch four-step path in every context (three persistent team kernels cannot share ONE device)
                                                            ("cu8", 256, 100, 2, sa.OUT_POW_F32)])
 def test_waterfall_multi_equals_the_single_context_tile(svc, oracle, datatype, nfft, hop, n_lines, fmt):
     """Three contexts (all on device 0 on the one-GPU box; one per GPU on a node), one host thread each inside the

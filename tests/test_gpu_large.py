@@ -167,6 +167,7 @@ def test_a_context_stops_trying_the_team_kernel_after_one_abort(oracle):
     try:
         datatype, nfft, hop, n_lines = "cf64_le", 16384, 8192, 70
         iq = torch.from_numpy(oracle.synth_iq(datatype, 13, 0, (n_lines - 1) * hop + nfft)).cuda()
+        s.set_option("large_single", 0)                    # (16384-point fp64 lines: the four-step paths are what this is about)
 
         def run():   # (the context has a stream of its own: wait for it before anything on torch's stream reads the tile)
             o = s.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, out_fmt=sa.OUT_POW_F64)
