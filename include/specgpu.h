@@ -150,6 +150,9 @@ void *spec_stream(const spec_ctx *ctx);
  *                     2 (default) = where it was measured faster than the family's kernel (everything but cf32 / ci16 at 75 %
  *                     overlap and cf32 at 50 % overlap without a window, where the family keeps the overlap in registers),
  *                     1 = always, 0 = never
+ *   "small_single" = 2 | 1 | 0   8192-point fp32 lines through it (16 points per thread and half, three workgroups per CU):
+ *                     2 (default) = cf32 where the family's kernel has no register-reuse variant (big-endian files, hops other
+ *                     than N/4, N/2, N; 8 ... 11 points of the roofline faster; level everywhere else), 1 = always, 0 = never
  *   "multi_verify" = 0 | 1   spec_waterfall_multi / spec_welch_psd_multi with a device-resident result: 1 = every piece a
  *                     peer context sends is checksummed on its own device before it leaves and again where it landed on
  *                     the consumer's device; a difference is SPEC_EDEVICE and the message names piece, devices and the path

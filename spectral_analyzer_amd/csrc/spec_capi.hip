@@ -76,6 +76,7 @@ struct spec_ctx {
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
     int64_t opt_large_team = 1, opt_large_ring = 0, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
     int64_t opt_large_single = 1;  // 32768-point fp32 lines in one workgroup (spec_k_v2h.hip); 0: the four-step path
+    int64_t opt_small_single = 2;  // 8192-point fp32 lines through the same kernel (16 points per thread and half): 2 where measured faster, 1 always, 0 never
     int64_t opt_mid_single = 2;    // 16384-point fp32 lines through the same kernel: 2 where measured faster (run_lines), 1 always, 0 never
     int64_t opt_welch_two_pass = 0;
     // the persistent large-N kernel: a launch whose abort word has not been looked at yet, and the verdict once a
@@ -371,6 +372,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "large_team_fake_abort")) c->opt_team_fake_abort = value != 0;
     else if (!strcmp(key, "large_single")) c->opt_large_single = value != 0;
     else if (!strcmp(key, "mid_single")) c->opt_mid_single = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(key, "small_single")) c->opt_small_single = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "multi_verify")) c->opt_multi_verify = value != 0;
     else if (!strcmp(key, "multi_verify_corrupt")) c->opt_multi_verify_corrupt = value != 0;
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
@@ -386,7 +388,7 @@ spec_status spec_get_option(spec_ctx *c, const char *key, int64_t *value) {
     struct { const char *k; int64_t v; } tab[] = {
         {"force_generic", c->opt_force_generic}, {"lines_per_wg", c->opt_lines_per_wg}, {"large_chunk_mb", c->opt_large_chunk_mb},
         {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass},
-        {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"mid_single", c->opt_mid_single},
+        {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"mid_single", c->opt_mid_single}, {"small_single", c->opt_small_single},
         {"large_block", c->opt_large_block}, {"render_fused", c->opt_render_fused}, {"readahead_lines", c->opt_readahead_lines},
         {"large_team_fake_abort", c->opt_team_fake_abort}, {"large_team_disabled", c->team_disabled ? 1 : 0},
         {"multi_verify", c->opt_multi_verify}, {"multi_verify_corrupt", c->opt_multi_verify_corrupt}, {"multi_peer_access", c->multi_peer_access}, {"multi_verified", c->multi_verified},
@@ -569,6 +571,13 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         const bool family_wins = (hop == nfft / 4 && le_wide) || (a.kind == K_CF32 && !a.be && hop == nfft / 2 && window == SPEC_WIN_RECT);
         mid_single = c->opt_mid_single == 1 || !family_wins;
     }
+    // 8192-point lines ("small_single", tools/bench_mid.py 8192, profiles/r04_small.txt): level with the family's kernel (+-2 points)
+    // except for cf32 where the family has no register-reuse variant -- big-endian files, and hops other than N/4, N/2, N --
+    // there 8 ... 11 points of the roofline faster (0.47 -> 0.56, 0.55 -> 0.66); not at hop = N (0.70 either way)
+    if (log2n == 13 && !f64 && !d_sel && !c->opt_force_generic && c->opt_small_single) {
+        const bool wins = a.kind == K_CF32 && hop != nfft && (a.be || (hop != nfft / 2 && hop != nfft / 4));
+        mid_single = c->opt_small_single == 1 || wins;
+    }
     if (((large && c->opt_large_single && c->opt_large_team == 1) || mid_single) && !f64 && !d_sel &&
         v2h_applicable(log2n, a.kind, a.out_fmt, n_lines, hop)) {
         // 32768-point fp32 lines: ONE workgroup per line -- a radix-2 step in registers, then two 16384-point transforms of
@@ -582,7 +591,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             const uint64_t rem = n_lines - done;
             // one workgroup per CU at a time and a set-up (twiddle tables, first line not prefetched) worth about a line: long
             // runs, two workgroups per CU when the recording is short (measured: runs of 32 against runs of 8, 44.6 % / 42.5 %)
-            const uint64_t wgs_wanted = (uint64_t)c->n_cu * (log2n == 15 ? 2 : 4);
+            const uint64_t wgs_wanted = (uint64_t)c->n_cu * (log2n == 15 ? 2 : log2n == 14 ? 4 : 8);
             uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg : (rem + wgs_wanted - 1) / wgs_wanted;
             if (run < 1) run = 1;
             if (run > 32) run = 32;  // (runs of 64: 42.8 %, of 32: 43.8 % on the same box)

@@ -70,11 +70,13 @@ __device__ static constexpr double kW64[32][2] = {
     {-0.980785280403230449126, -0.195090322016128267848},
     {-0.995184726672196886245, -0.0980171403295606019942}};
 
-// d * W_64^M * wt
-template <int M> __device__ __forceinline__ v2f v2h_twiddle(v2f d, v2f wt) {
+// d * W_NT^M * wt, NT = N / T = 64 (32 points per thread and half) or 32 (16 points)
+template <int M, int NT> __device__ __forceinline__ v2f v2h_twiddle(v2f d, v2f wt) {
+    static_assert(NT == 64 || NT == 32, "per-thread stride of the line");
     if constexpr (M == 0) return pk_cmul(d, wt);
-    else if constexpr (M == 16) return pk_cmul(pk_mul_mi(d), wt);
-    else return pk_cmul(pk_cmul_const(d, kW64[M][0], kW64[M][1]), wt);
+    else if constexpr (M == NT / 4) return pk_cmul(pk_mul_mi(d), wt);
+    else if constexpr (NT == 64) return pk_cmul(pk_cmul_const(d, kW64[M][0], kW64[M][1]), wt);
+    else return pk_cmul(pk_cmul_const(d, kW32[M][0], kW32[M][1]), wt);
 }
 template <typename F, int... M> __device__ __forceinline__ void v2h_for_each(F &&f, std::integer_sequence<int, M...>) {
     (f(std::integral_constant<int, M>{}), ...);
@@ -148,17 +150,22 @@ template <bool BOUNDED, int E> __device__ __forceinline__ void v2h_epilogue(cons
 
 // REUSE: hop == N/2 and a 2- / 4-byte format -- the raw upper half stays in registers as the next line's lower half
 // L: log2 of the HALF line (14: 32768-point lines, one 512-thread workgroup per CU; 13: 16384-point lines, 256-thread
-// workgroups, two per CU -- two independent barrier domains on every SIMD)
+// workgroups, two per CU -- two independent barrier domains on every SIMD; 12: 8192-point lines, 16 points per thread and
+// half, 256-thread workgroups at V2H_WAVES_12 waves per SIMD)
+#ifndef V2H_WAVES_12
+#define V2H_WAVES_12 3
+#endif
 template <int L, int KIND, bool HAS_WIN, bool BE, bool REUSE>
-__global__ __launch_bounds__(Plan2<L>::T, 2) void v2h_kernel(const V2hArgs a) {
+__global__ __launch_bounds__(Plan2<L>::T, L == 12 ? V2H_WAVES_12 : 2) void v2h_kernel(const V2hArgs a) {
     using PL = Plan2<L>;
     using RW = Raw2<KIND>;
     using raw_t = typename RW::type;
     constexpr int BPS = RW::BPS, H = PL::N, N = 2 * H, T = PL::T, E = PL::E;
     constexpr bool PARK_RAW = KIND != K_CF32;  // park the raw samples (E + E registers) instead of the decoded difference
-    constexpr int PF = V2H_PF;
+    constexpr int PF = V2H_PF < E ? V2H_PF : E;
+    constexpr int NT = N / T;
     static_assert(!REUSE || PARK_RAW, "register reuse needs the raw halves parked");
-    static_assert(E == 32 && N / T == 64, "32 points per thread and half: n = t + T m, W_N^(T m) = W_64^m");
+    static_assert((E == 32 && NT == 64) || (E == 16 && NT == 32), "n = t + T m, W_N^(T m) = W_NT^m, m < NT / 2");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     v2f *lds = reinterpret_cast<v2f *>(smem);
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(Plan2<L>::T, 2) void v2h_kernel(const V2hArgs a) {
 
     fill_tables<L, 1>(tab, tw, t);
     v2f *wtab = tab + p2_tab_entries<L>();  // W_64^m = W_N^(512 m), m < 32 (the Hann window's cosine, below)
-    if (HAS_WIN && t < 32) wtab[t] = static_cast<const v2f *>(a.tw_full)[T * t];
+    if (HAS_WIN && t < E) wtab[t] = static_cast<const v2f *>(a.tw_full)[T * t];
     v2f twl[16];
 #pragma unroll
     for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (H - 1)];
@@ -246,9 +253,9 @@ __global__ __launch_bounds__(Plan2<L>::T, 2) void v2h_kernel(const V2hArgs a) {
                 // decode's floats instead (128 registers alive across the first transform)
                 asm volatile("" : "+v"(rlo[m]), "+v"(rhi[m]));
                 decode(m, lo, hi);
-                v[m] = v2h_twiddle<m>(lo - hi, wt);
+                v[m] = v2h_twiddle<m, NT>(lo - hi, wt);
             } else {
-                v[m] = v2h_twiddle<m>(dd[m], wt);
+                v[m] = v2h_twiddle<m, NT>(dd[m], wt);
             }
         }, std::make_integer_sequence<int, E>{});
         if constexpr (PARK_RAW) {  // the whole next line is requested here and lands behind the second transform
@@ -313,7 +320,7 @@ template <int L> hipError_t v2h_launch_l(const V2hArgs &a, int kind, int be, hip
 }  // namespace
 
 bool v2h_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop) {
-    if (log2n != 15 && log2n != 14) return false;
+    if (log2n != 15 && log2n != 14 && log2n != 13) return false;
     if (kind != K_CF32 && kind != K_CI16 && kind != K_CU8 && kind != K_CI8) return false;
     if (out_fmt != OUT_DB20_F32 && out_fmt != OUT_POW_F32) return false;
     return n_lines > 0 && n_lines < (1ull << 31) && hop <= (8u << log2n);  // a workgroup's span stays far below 4 GiB
@@ -324,7 +331,7 @@ hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, u
     a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.run = run;
     a.tw_half = tw_half; a.tw_full = w.tw; a.win = w.win;
     a.out = static_cast<float *>(w.out); a.out_fmt = w.out_fmt;
-    return log2n == 15 ? v2h_launch_l<14>(a, w.kind, w.be, s) : v2h_launch_l<13>(a, w.kind, w.be, s);
+    return log2n == 15 ? v2h_launch_l<14>(a, w.kind, w.be, s) : log2n == 14 ? v2h_launch_l<13>(a, w.kind, w.be, s) : v2h_launch_l<12>(a, w.kind, w.be, s);
 }
 
 }  // namespace specgpu

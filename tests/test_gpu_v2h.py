@@ -15,6 +15,7 @@ from test_gpu_parity import check_fp32
 pytestmark = pytest.mark.gpu
 
 NFFT = 32768
+SMALL_DEFAULT = 2    # "small_single": the default rule
 
 
 @pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8"])
@@ -107,20 +108,22 @@ def test_every_value_at_full_size(svc):
 
 
 @pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be", "ci16_le", "cu8", "ci8"])
-@pytest.mark.parametrize("hop,window", [(8192, sa.WIN_RECT), (16384, sa.WIN_HANN), (4096, sa.WIN_RECT), (5000, sa.WIN_HANN)])
-def test_half_line_kernel_at_16384_points(svc, oracle, datatype, hop, window):
-    """The same kernel one size down (256-thread workgroups, two per CU; "mid_single" = 1 forces it, the default takes it
-    where it was measured faster than the family's 16384-point kernel): against the oracle, and the family's kernel
-    ("mid_single" = 0) agrees to fp32 rounding."""
+@pytest.mark.parametrize("hop_num,window", [(2, sa.WIN_RECT), (4, sa.WIN_HANN), (1, sa.WIN_RECT), (0, sa.WIN_HANN)])
+@pytest.mark.parametrize("nfft,knob", [(16384, "mid_single"), (8192, "small_single")])
+def test_half_line_kernel_at_16384_and_8192_points(svc, oracle, datatype, hop_num, window, nfft, knob):
+    """The same kernel one and two sizes down (256-thread workgroups, two / three per CU; the knob = 1 forces it, 2 takes it
+    where it was measured faster than the family's kernel of that size): against the oracle, and the family's kernel
+    (knob = 0) agrees to fp32 rounding."""
     import torch
-    nfft, n_lines = 16384, 10
+    n_lines = 10
+    hop = hop_num * nfft // 4 if hop_num else 5000
     iq = oracle.synth_iq(datatype, seed=hop + window + 1, first_sample=2, n_samples=(n_lines - 1) * hop + nfft)
     ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines + 1, window=window)
     d = torch.from_numpy(iq).cuda()
     try:
         out = {}
         for mode in (1, 0, 2):
-            svc.set_option("mid_single", mode)
+            svc.set_option(knob, mode)
             got = svc.compute_waterfall(d, 0, nfft, datatype, n_lines + 1, hop=hop, window=window)
             torch.cuda.synchronize()
             out[mode] = got.cpu().numpy()
@@ -129,4 +132,4 @@ def test_half_line_kernel_at_16384_points(svc, oracle, datatype, hop, window):
         assert not np.array_equal(out[1], out[0])                       # two different kernels
         assert np.array_equal(out[2], out[1]) or np.array_equal(out[2], out[0])
     finally:
-        svc.set_option("mid_single", 2)
+        svc.set_option(knob, 2 if knob == "mid_single" else SMALL_DEFAULT)
