@@ -83,6 +83,7 @@ VARIANTS = {
     "v2hpf20": (["-DV2H_PF=20"], ["spec_k_v2h.hip"]),
     "v2hw4": (["-DV2H_WAVES_12=4"], ["spec_k_v2h.hip"]),
     "v2hw2": (["-DV2H_WAVES_12=2"], ["spec_k_v2h.hip"]),
+    "v3hhi": (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"]),
     "v3he48": (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"]),
     "v3he64": (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"]),
 }

@@ -109,6 +109,9 @@ __device__ __forceinline__ void v3h_fft(v2d (&v)[16], int t, v2d *lds, const v2d
     }
 }
 
+#ifndef V3H_EARLY_LO_FIRST
+#define V3H_EARLY_LO_FIRST 1
+#endif
 #ifndef V3H_EARLY_REGS
 #define V3H_EARLY_REGS 32  // registers' worth of the next line requested BEFORE the second transform (cf64: 8 of 32 samples)
 #endif
@@ -122,11 +125,15 @@ __global__ __launch_bounds__(Plan2<113>::T, 2) void v3h_kernel(const V3hArgs a) 
     constexpr int BPS = RW::BPS, H = PL::N, N = 2 * H, T = PL::T, E = PL::E;
     constexpr bool PARK_RAW = KIND != K_CF64;
     constexpr int RAW_REGS = sizeof(raw_t) <= 4 ? 1 : (int)sizeof(raw_t) / 4;
-    // the part of the next line requested BEFORE the second transform -- the upper half first (new samples at 50 % overlap,
-    // the lower half comes back from L2 / the Infinity Cache); the rest is requested behind the second epilogue
+    // the part of the next line requested BEFORE the second transform; the rest is requested behind the second epilogue.
+    // The LOWER half first: at 50 % overlap it is the half this workgroup read one line ago, and the sooner it is read again
+    // the more of it is still in L2 (each CU keeps 128 KiB in flight there, 4 MiB per XCD -- all of the L2; with the upper
+    // half first, 1.5 line times between the two readings, none of it was: reads 1.9x the new samples, V3H_EARLY_LO_FIRST = 0)
     constexpr int N_EARLY = (V3H_EARLY_REGS - (REUSE ? E * RAW_REGS : 0)) / RAW_REGS;  // (REUSE: the kept half counts)
-    constexpr int EARLY_HI = N_EARLY < E ? N_EARLY : E;
-    constexpr int EARLY_LO = REUSE ? 0 : (N_EARLY - EARLY_HI < E ? N_EARLY - EARLY_HI : E);
+    constexpr bool LO_FIRST = V3H_EARLY_LO_FIRST && !REUSE;
+    constexpr int EARLY_A = N_EARLY < E ? N_EARLY : E, EARLY_B = N_EARLY - EARLY_A < E ? N_EARLY - EARLY_A : E;
+    constexpr int EARLY_LO = REUSE ? 0 : (LO_FIRST ? EARLY_A : EARLY_B);
+    constexpr int EARLY_HI = LO_FIRST ? EARLY_B : EARLY_A;
     static_assert(!REUSE || PARK_RAW, "register reuse needs the raw halves parked");
     static_assert(E == 16 && N / T == 32, "16 points per thread and half: n = t + T m, W_N^(T m) = W_32^m");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
