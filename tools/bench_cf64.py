@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The fp64 (strict-parity) pipeline: cf64 recordings and fp64 outputs at 1024 / 4096 / 8192 points,
+"""The fp64 (strict-parity) pipeline: cf64 recordings and fp64 outputs at 1024 / 4096 / 8192 / 16384 points,
 50 % overlap (development tool; HIP-event medians).   python tools/bench_cf64.py [log2_samples=27] [nfft ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,7 @@ def timeit(fn, reps=8, warm=6):
     torch.cuda.synchronize()
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
-for nfft in ([int(x) for x in sys.argv[2:]] or (1024, 4096, 8192)):
+for nfft in ([int(x) for x in sys.argv[2:]] or (1024, 4096, 8192, 16384)):
     for dt, fmt, label in (("cf64_le", sa.OUT_DB20_F64, "cf64->f64"), ("cf64_le", sa.OUT_DB20_F32, "cf64->f32"),
                            ("cf32_le", sa.OUT_DB20_F64, "cf32->f64")):
         hop, S, bps = nfft // 2, 1 << log2s, sa.bytes_per_sample(dt)
