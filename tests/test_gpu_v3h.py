@@ -93,3 +93,43 @@ def test_extreme_magnitudes_take_the_general_form(svc, oracle):
     assert np.all(np.isnan(got[3]))
     assert np.all(np.isfinite(got[1:3]))
     check_fp64(got[1:3], ref[1:3])
+
+
+def test_every_value_at_full_size(svc):
+    """2^27 cf64 samples, 16 383 lines of 16384 points at 50 % overlap: all 16 383 x 16 384 power values of the single-workgroup
+    kernel against the two-launch four-step path ("large_single" = 0, "large_team" = 0) on the device, |dP| <= the fp64 power
+    tolerance of the line's peak; repeated launches bit-identical (the store hazard of DESIGN.md 4.4d showed up as one run in
+    three differing in a few bins); Parseval on every 97th line."""
+    import torch
+    datatype, hop, S = "cf64_le", 8192, 1 << 27
+    n_lines = (S - NFFT) // hop + 1
+    iq = svc.synth_iq(datatype, 0x5EC7A11A, 0, S)
+    try:
+        one = svc.compute_waterfall(iq, 0, NFFT, datatype, n_lines, hop=hop, out_fmt=sa.OUT_POW_F64)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            again = svc.compute_waterfall(iq, 0, NFFT, datatype, n_lines, hop=hop, out_fmt=sa.OUT_POW_F64)
+            torch.cuda.synchronize()
+            assert torch.equal(one, again)
+            del again
+        svc.set_option("large_single", 0)
+        svc.set_option("large_team", 0)
+        two = svc.compute_waterfall(iq, 0, NFFT, datatype, n_lines, hop=hop, out_fmt=sa.OUT_POW_F64)
+        torch.cuda.synchronize()
+        worst, bad, tol = 0.0, 0, fp64_pow_tol(NFFT)
+        for a in range(0, n_lines, 2048):
+            t, w = one[a:a + 2048], two[a:a + 2048]
+            rel = ((t - w).abs() / w.amax(dim=1, keepdim=True)).amax(dim=1)
+            worst = max(worst, float(rel.max()))
+            bad += int((rel > tol).sum())
+        assert bad == 0 and worst <= tol, (bad, worst)
+        assert bool(torch.isfinite(one).all())
+        x = iq.view(torch.float64).view(-1, 2)
+        for ln in range(0, n_lines, 97):                   # sum |X|^2 = N sum |x|^2
+            e = float((x[ln * hop:ln * hop + NFFT] ** 2).sum()) * NFFT
+            assert float(one[ln].sum()) == pytest.approx(e, rel=1e-11)
+    finally:
+        svc.set_option("large_team", 1)
+        svc.set_option("large_single", 1)
+        del iq
+        torch.cuda.empty_cache()
