@@ -85,6 +85,9 @@ VARIANTS = {
     "v2hpf20": (["-DV2H_PF=20"], ["spec_k_v2h.hip"]),
     "v2hw4": (["-DV2H_WAVES_12=4"], ["spec_k_v2h.hip"]),
     "v2hw2": (["-DV2H_WAVES_12=2"], ["spec_k_v2h.hip"]),
+    # fp64 family: last-pass twiddles in registers (rounds 1-3) / in LDS without the cf64 / cf32 prefetch
+    "v3dreg": (["-DSPEC_V3D_LDS_TWL=0"], ["spec_k_v3d.hip"]),
+    "v3dnp": (["-DSPEC_V3D_PREFETCH_ALL=0"], ["spec_k_v3d.hip"]),
     "v3hhi": (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"]),
     "v3he48": (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"]),
     "v3he64": (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"]),

@@ -12,6 +12,61 @@ namespace specgpu {
 
 namespace {
 
+// Last-pass twiddles W_N^(r t), r = 1 .. 15, from two LDS tables instead of 60 registers per thread (round 4, as
+// spec_k_v3h.hip): t = j + J h, W_N^(r t) = W_N^(r j) W_N^(r J h) -- one more complex product per point of the last pass,
+// 30 table reads per line; the registers hold the next line's samples in flight for cf64 / cf32 input as well.
+#ifndef SPEC_V3D_LDS_TWL
+#define SPEC_V3D_LDS_TWL 1
+#endif
+#ifndef SPEC_V3D_PREFETCH_ALL
+#define SPEC_V3D_PREFETCH_ALL 1
+#endif
+template <int L> struct V3dTw {
+    using PL = Plan2<L>;
+    static constexpr int J = PL::T < 32 ? PL::T : 32, HB = PL::T / J;
+    static constexpr int ENTRIES = 15 * J + (HB > 1 ? 15 * HB : 0);
+    // 8192 points only: 0.36 -> 0.43 of 8 TB/s (cf64 -> f64; the registers' 60 hold the next line in flight).  Measured
+    // slower at 4096 points (0.51 -> 0.45: the tables take the second workgroup's LDS) and at 1024 (0.58 -> 0.56).
+    static constexpr bool USE = SPEC_V3D_LDS_TWL != 0 && L == 113;
+    static constexpr size_t BYTES = USE ? (size_t)ENTRIES * sizeof(v2d) : 0;
+};
+template <int L> __device__ __forceinline__ void v3d_fill_twl(v2d *tl, const v2d *__restrict__ tw, int tid) {
+    using W = V3dTw<L>;
+    for (int e = tid; e < W::ENTRIES; e += Plan2<L>::WG) {
+        if (e < 15 * W::J) tl[e] = tw[(e / W::J + 1) * (e % W::J)];
+        else { const int f = e - 15 * W::J; tl[e] = tw[(f / W::HB + 1) * W::J * (f % W::HB)]; }
+    }
+}
+template <int L, int PASS = 0>
+__device__ __forceinline__ void v3d_fft(v2d (&v)[Plan2<L>::E], int t, v2d *lds, const v2d *tab, const v2d *tl) {
+    using PL = Plan2<L>;
+    using W = V3dTw<L>;
+    if constexpr (PASS + 1 < PL::NPASS) {
+        v2d none[16];  // (only the last pass reads its twiddle registers)
+        v2_pass<L, PASS>(v, t, tab, none);
+        v2_sync<L>();  // WAR: the previous exchange has been read by everyone
+        v2_store<L, PASS>(v, t, lds);
+        v2_sync<L>();
+        v2_load<L, PASS>(v, t, lds);
+        v3d_fft<L, PASS + 1>(v, t, lds, tab, tl);
+    } else {
+        static_assert(PL::radix[PASS] == 16 && PL::E == 16, "last pass: one radix-16 butterfly per thread");
+        const v2d *ra = tl + (t & (W::J - 1));
+        const v2d *rb = tl + 15 * W::J + (t / W::J);
+        // five at a time: left alone the scheduler requests every table entry first (120 registers)
+#pragma unroll
+        for (int r0 = 1; r0 < 16; r0 += 5) {
+#pragma unroll
+            for (int r = r0; r < r0 + 5; ++r) {
+                if constexpr (W::HB > 1) v[r] = pk_cmul(v[r], pk_cmul(ra[(r - 1) * W::J], rb[(r - 1) * W::HB]));
+                else v[r] = pk_cmul(v[r], ra[(r - 1) * W::J]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        pk_dft16(v);
+    }
+}
+
 // MODE 0: spectrogram lines (MC:980-999 around SS:33-85), fp64 arithmetic; doubles or floats out.
 // MODE 1: Welch partial sums in fp64 (the dialog's calculatePsdWelch call, ADC:308-312, and cf64 / big-endian /
 // fp64-output PSDs): every sub-line adds |X|^2 of its run of segments in registers and leaves ONE double slab;
@@ -37,11 +92,17 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
         for (int e = tid; e < DB20_TAB_DOUBLES; e += PL::WG) dbt_w[e] = DB20_TAB[e];
     }
     (void)dbt;
+    constexpr bool LDS_TWL = V3dTw<L>::USE;
+    v2d *tl = reinterpret_cast<v2d *>(smem + p2_lds_bytes<L, 16>() + (MODE == 0 ? DB20_TAB_DOUBLES * sizeof(double) : 0));
     v2d twl[16];
+    if constexpr (LDS_TWL) {
+        v3d_fill_twl<L>(tl, tw, tid);
+    } else {
 #pragma unroll
-    for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+        for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    }
     const double *win = static_cast<const double *>(a.win);
-    if constexpr (PL::NPASS > 2 || MODE == 0) __syncthreads();
+    if constexpr (PL::NPASS > 2 || MODE == 0 || LDS_TWL) __syncthreads();
 
     const uint32_t unit = blockIdx.x / a.wgs_per_unit, wg = blockIdx.x % a.wgs_per_unit;
     const uint32_t line0 = wg * (uint32_t)PL::LPW * a.run;
@@ -58,7 +119,9 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
     // (16 / 16 registers).  For cf32 / cf64 the 32 / 64 registers of a second line push the kernel over its
     // 256 and the spills cost more than the prefetch hides (measured: cf64 4096-pt 37 -> 46 M lines/s,
     // cf32 -> f64 51 -> 53 M lines/s without it); those load each line at its start.
-    constexpr bool PREFETCH = KIND != K_CF64 && KIND != K_CF32;
+    // (With the last pass's twiddles in LDS every format has the room.)
+    // (Welch keeps the old rule: 16 more registers of sums, and its overlap is re-read from L2 anyway.)
+    constexpr bool PREFETCH = (KIND != K_CF64 && KIND != K_CF32) || (LDS_TWL && SPEC_V3D_PREFETCH_ALL != 0 && MODE == 0);
     raw_t raw[E];
     if constexpr (PREFETCH) {
 #pragma unroll
@@ -106,7 +169,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
             for (int m = E - NEW; m < E; ++m) raw[m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
         }
 
-        v2_fft<L>(v, t, lds, tab, twl);
+        if constexpr (LDS_TWL) v3d_fft<L>(v, t, lds, tab, tl);
+        else v2_fft<L>(v, t, lds, tab, twl);
 
         if constexpr (MODE == 1) {
             if (line < my_lines) {
@@ -155,7 +219,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
 template <int L, int KIND, int SH, bool HAS_WIN, bool BE = false, int MODE = 0>
 hipError_t v3d_launch1(const V2Args &a, hipStream_t s) {
     using PL = Plan2<L>;
-    constexpr size_t lds = p2_lds_bytes<L, 16>() + (MODE == 0 ? DB20_TAB_DOUBLES * sizeof(double) : 0);
+    constexpr size_t lds = p2_lds_bytes<L, 16>() + (MODE == 0 ? DB20_TAB_DOUBLES * sizeof(double) : 0) + V3dTw<L>::BYTES;
+    static_assert(lds <= 160 * 1024, "one workgroup's LDS");
     auto kern = v3d_kernel<L, KIND, SH, HAS_WIN, BE, MODE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
