@@ -88,6 +88,8 @@ VARIANTS = {
     # fp64 family: last-pass twiddles in registers (rounds 1-3) / in LDS without the cf64 / cf32 prefetch
     "v3dreg": (["-DSPEC_V3D_LDS_TWL=0"], ["spec_k_v3d.hip"]),
     "v3dnp": (["-DSPEC_V3D_PREFETCH_ALL=0"], ["spec_k_v3d.hip"]),
+    # 32-point-per-thread plans: the window re-read from the L2-resident table every line (rounds 1-3) instead of a quarter Hann table in LDS
+    "v2wg": (["-DSPEC_V2_WIN_LDS=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip"]),
     "v3hhi": (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"]),
     "v3he48": (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"]),
     "v3he64": (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"]),

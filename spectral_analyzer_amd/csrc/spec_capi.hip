@@ -560,16 +560,25 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     if (st != SPEC_OK) return st;
     st = get_window(c, log2n, f64, window, &a.win, nullptr, nullptr);
     if (st != SPEC_OK) return st;
+    a.win_hann = window == SPEC_WIN_HANN;
     const uint64_t out_esz = fmt >= SPEC_OUT_DB20_F64 ? 8 : 4, nfft = 1ull << log2n;
-    // 16384-point lines the same way (256-thread workgroups, two per CU) where that is faster than the family's kernel
-    // -- measured case by case, tools/bench_mid.py: everywhere (by 2 ... 10 points of the roofline) except where the family
-    // keeps the overlap in registers and has no window to fetch: cf32 / ci16 at 75 % overlap, cf32 at 50 % without a window.
-    // "mid_single" = 2 (default) that rule, 1 always, 0 never.
+    // 16384-point lines the same way (256-thread workgroups, two per CU) where that is faster than the family's kernel --
+    // measured case by case (tools/bench_mid.py, profiles/r04_mid.txt; re-measured after the family's 32-point threads got their
+    // Hann window from LDS, which turned every windowed case but two its way).  "mid_single" = 2 (default) that rule, 1 always, 0 never:
+    //   big-endian cf32 / ci16: half-line below hop = N (the family has one variant without register reuse: 0.32-0.42 vs 0.36-0.46)
+    //   with a window: the family, except cf32 at hops other than N/4, N/2, N (0.49 vs 0.51)
+    //   without: cf32 half-line at hops other than N/4, N/2 (the family keeps the overlap in registers there: 0.43 / 0.52 vs 0.37 / 0.48);
+    //            ci16 half-line except at N/4; cu8 / ci8 half-line (+1 ... 2 points)
     bool mid_single = false;
     if (log2n == 14 && !f64 && !d_sel && !c->opt_force_generic && c->opt_mid_single) {
-        const bool le_wide = !a.be && (a.kind == K_CF32 || a.kind == K_CI16);
-        const bool family_wins = (hop == nfft / 4 && le_wide) || (a.kind == K_CF32 && !a.be && hop == nfft / 2 && window == SPEC_WIN_RECT);
-        mid_single = c->opt_mid_single == 1 || !family_wins;
+        const bool reuse_hop = hop == nfft / 4 || hop == nfft / 2;
+        bool half;
+        if (a.be && (a.kind == K_CF32 || a.kind == K_CI16)) half = hop != nfft;
+        else if (window != SPEC_WIN_RECT) half = a.kind == K_CF32 && !reuse_hop && hop != nfft;
+        else if (a.kind == K_CF32) half = !reuse_hop;
+        else if (a.kind == K_CI16) half = hop != nfft / 4;
+        else half = true;
+        mid_single = c->opt_mid_single == 1 || half;
     }
     // 8192-point lines ("small_single", tools/bench_mid.py 8192, profiles/r04_small.txt): level with the family's kernel (+-2 points)
     // except for cf32 where the family has no register-reuse variant -- big-endian files, and hops other than N/4, N/2, N --
@@ -1571,6 +1580,7 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         // packed-fp32 family: sub-lines accumulate |X|^2 over runs of segments, one slab each
         st = get_window(c, log2n, false, window, &a.win, &s1, &s2, /*table_for_rect=*/true);
         if (st != SPEC_OK) return st;
+        a.win_hann = window == SPEC_WIN_HANN;
         const uint32_t sub = (uint32_t)v2_lpw(log2n);
         // enough sub-lines to fill the chip first (a single 256-segment PSD gets one segment per
         // sub-line), long runs (register reuse, fewer slabs) once there is plenty of work

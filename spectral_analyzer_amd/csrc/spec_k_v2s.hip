@@ -29,7 +29,7 @@ hipError_t launch_v2_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream
     a.iq = w.iq; a.unit_stride = 0; a.n_units = 1; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.run = run;
     const uint32_t per_wg = (uint32_t)v2_lpw(log2n) * run;
     a.wgs_per_unit = (a.n_lines + per_wg - 1) / per_wg;
-    a.tw = w.tw; a.win = w.win; a.out = w.out; a.out_fmt = w.out_fmt; a.be = w.be;
+    a.tw = w.tw; a.win = w.win; a.out = w.out; a.out_fmt = w.out_fmt; a.be = w.be; a.win_hann = w.win_hann;
     return v2_launch_n<0>(a, log2n, w.kind, s);
 }
 

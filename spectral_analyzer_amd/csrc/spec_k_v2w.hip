@@ -9,7 +9,7 @@ namespace specgpu {
 hipError_t launch_v2_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t wgs_per_unit, hipStream_t s) {
     V2Args a{};
     a.iq = w.iq; a.unit_stride = w.psd_stride_bytes; a.n_units = w.n_psd; a.n_lines = w.n_seg; a.hop = w.hop;
-    a.run = run; a.wgs_per_unit = wgs_per_unit; a.tw = w.tw; a.win = w.win; a.out = w.partial; a.out_fmt = 0; a.be = w.be;
+    a.run = run; a.wgs_per_unit = wgs_per_unit; a.tw = w.tw; a.win = w.win; a.out = w.partial; a.out_fmt = 0; a.be = w.be; a.win_hann = w.win_hann;
     a.final_out = wgs_per_unit == 1 && v2_lpw(log2n) == 1 ? w.final_out : nullptr; a.norm = w.norm; a.db = w.db;
     return v2_launch_n<1>(a, log2n, w.kind, s);
 }

@@ -325,6 +325,9 @@ __device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, floa
     }
 }
 
+#ifndef SPEC_V2_WIN_LDS
+#define SPEC_V2_WIN_LDS 1
+#endif
 struct V2Args {
     const uint8_t *iq;      // first byte of unit 0, line 0
     uint64_t unit_stride;   // bytes between units (Welch: PSDs; spectrogram: one unit)
@@ -332,6 +335,7 @@ struct V2Args {
     uint32_t hop, run;      // samples between lines; lines per sub-line run
     uint32_t wgs_per_unit;
     const void *tw, *win;
+    int win_hann;           // `win` is the periodic Hann table: 32-point threads read a quarter of it from LDS (below)
     void *out;              // spectrogram: float[n_lines][N]; Welch: float slabs [unit][wg*LPW + q][N]
     int out_fmt;
     int be;                 // big-endian components
@@ -370,6 +374,16 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     if constexpr (WIN_REGS) {
 #pragma unroll
         for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
+    }
+    // Round 4: the Hann window of the 32-point threads from LDS.  w[N/2 - n] = 1 - w[n] and w[n + N/2] = 1 - w[n] leave N/4 + 1
+    // distinct values (16 KiB at 16384 points: what the LDS has left); 16 LDS reads and 16 subtractions per line instead of 32
+    // loads from L2 whose latency the two waves of a SIMD waited out in lock step at the top of every line.
+    constexpr bool WIN_LDS = HAS_WIN && E == 32 && SPEC_V2_WIN_LDS != 0;
+    float *wq = reinterpret_cast<float *>(smem + p2_lds_bytes<L>());
+    const bool hann_lds = WIN_LDS && a.win_hann != 0;
+    if constexpr (WIN_LDS) {
+        if (hann_lds)
+            for (int e = tid; e <= N / 4; e += PL::WG) wq[e] = win[e];
     }
     // (the barrier that publishes the tables comes after the first line's loads have been issued)
 
@@ -436,10 +450,20 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
         constexpr int PH = PINGPONG ? decltype(phase_tag)::value : 0;  // physical register of sample m: (m + PH*SH) mod E
         v2f v[E];
         if constexpr (HAS_WIN && !WIN_REGS) {
-            const float *wp = win;
-            asm volatile("" : "+s"(wp));  // keep the loads inside the loop (LICM would pin E VGPRs)
+            if (hann_lds) {
+                const float *q0 = wq + t, *q1 = wq + (N / 2 - t);
 #pragma unroll
-            for (int m = 0; m < E; ++m) w[m] = wp[t + m * T];
+                for (int m = 0; m < E / 2; ++m) {  // n = t + m T < N/2;  w[N/2 - n] = 1 - w[n],  w[n + N/2] = 1 - w[n]
+                    const float x = m < E / 4 ? q0[m * T] : q1[-m * T];
+                    w[m] = m < E / 4 ? x : 1.0f - x;
+                    w[m + E / 2] = m < E / 4 ? 1.0f - x : x;
+                }
+            } else {
+                const float *wp = win;
+                asm volatile("" : "+s"(wp));  // keep the loads inside the loop (LICM would pin E VGPRs)
+#pragma unroll
+                for (int m = 0; m < E; ++m) w[m] = wp[t + m * T];
+            }
         }
 #pragma unroll
         for (int m = 0; m < E; ++m) {
@@ -527,7 +551,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 template <int L, int KIND, int SH, bool HAS_WIN, int MODE, bool BE = false>
 hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
     using PL = Plan2<L>;
-    constexpr size_t lds = p2_lds_bytes<L>();
+    constexpr size_t lds = p2_lds_bytes<L>() + (HAS_WIN && PL::E == 32 && SPEC_V2_WIN_LDS != 0 ? ((size_t)PL::N / 4 + 1) * sizeof(float) : 0);
+    static_assert(lds <= 160 * 1024, "one workgroup's LDS");
     // Minimum waves per SIMD asked of the register allocator, chosen so that the kernel does
     // not spill: about 104 VGPRs of FFT state + 32 (cf32) or 16 raw sample registers + 16 for a
     // window + 16 for Welch sums.  32-point threads (8192 / 16384 points) take the full 256.
