@@ -1580,7 +1580,7 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         // packed-fp32 family: sub-lines accumulate |X|^2 over runs of segments, one slab each
         st = get_window(c, log2n, false, window, &a.win, &s1, &s2, /*table_for_rect=*/true);
         if (st != SPEC_OK) return st;
-        a.win_hann = window == SPEC_WIN_HANN;
+        a.win_hann = window == SPEC_WIN_HANN ? 1 : 2;  // (2: the table of ones the rectangular Welch multiplies by)
         const uint32_t sub = (uint32_t)v2_lpw(log2n);
         // enough sub-lines to fill the chip first (a single 256-segment PSD gets one segment per
         // sub-line), long runs (register reuse, fewer slabs) once there is plenty of work

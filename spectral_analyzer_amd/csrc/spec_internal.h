@@ -21,7 +21,7 @@ struct WfArgs {
     int be;              // big-endian components
     const void *tw;      // cx<R>[N] twiddle table W_N^m
     const void *win;     // R[N] window or nullptr (rectangular)
-    int win_hann = 0;    // `win` is the periodic Hann table (w[N/2 - n] = w[n + N/2] = 1 - w[n]: spec_v2.h keeps a quarter of it in LDS)
+    int win_hann = 0;    // 1: `win` is the periodic Hann table (w[N/2 - n] = w[n + N/2] = 1 - w[n]: spec_v2.h keeps a quarter of it in LDS)
     void *out;           // n_lines x N, row-major
     int out_fmt;
     uint32_t lines_per_wg;  // contiguous lines handled by one workgroup (multiple of LPW)
@@ -36,7 +36,7 @@ struct WelchArgs {
     uint32_t hop, bps;
     int kind, be;
     const void *tw, *win;
-    int win_hann = 0;           // as WfArgs
+    int win_hann = 0;           // as WfArgs; 2: `win` is all ones (rectangular Welch)
     void *partial;              // [n_psd][slabs][N] unshifted power sums (fp32; fp64 for launch_v3d_welch)
     // launch_v2_welch with ONE workgroup and ONE sub-line per PSD (wgs_per_unit == 1, whole-workgroup lines): the
     // kernel finishes the PSD itself -- sum * norm, fftshift, optional 10 log10 -- into final_out (float[n_psd][N])

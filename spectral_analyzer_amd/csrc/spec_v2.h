@@ -335,7 +335,7 @@ struct V2Args {
     uint32_t hop, run;      // samples between lines; lines per sub-line run
     uint32_t wgs_per_unit;
     const void *tw, *win;
-    int win_hann;           // `win` is the periodic Hann table: 32-point threads read a quarter of it from LDS (below)
+    int win_hann;           // 1: `win` is the periodic Hann table (32-point threads read a quarter of it from LDS, below); 2: all ones
     void *out;              // spectrogram: float[n_lines][N]; Welch: float slabs [unit][wg*LPW + q][N]
     int out_fmt;
     int be;                 // big-endian components
@@ -380,7 +380,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     // loads from L2 whose latency the two waves of a SIMD waited out in lock step at the top of every line.
     constexpr bool WIN_LDS = HAS_WIN && E == 32 && SPEC_V2_WIN_LDS != 0;
     float *wq = reinterpret_cast<float *>(smem + p2_lds_bytes<L>());
-    const bool hann_lds = WIN_LDS && a.win_hann != 0;
+    const bool hann_lds = WIN_LDS && a.win_hann == 1;
+    const bool ones = WIN_LDS && a.win_hann == 2;  // the rectangular Welch's table of ones: nothing to read
     if constexpr (WIN_LDS) {
         if (hann_lds)
             for (int e = tid; e <= N / 4; e += PL::WG) wq[e] = win[e];
@@ -458,6 +459,9 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
                     w[m] = m < E / 4 ? x : 1.0f - x;
                     w[m + E / 2] = m < E / 4 ? 1.0f - x : x;
                 }
+            } else if (ones) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) w[m] = 1.0f;
             } else {
                 const float *wp = win;
                 asm volatile("" : "+s"(wp));  // keep the loads inside the loop (LICM would pin E VGPRs)
