@@ -8,6 +8,8 @@ import spectral_analyzer_amd as sa
 from test_gpu_parity import check_fp32, check_fp64
 
 pytestmark = pytest.mark.gpu
+# one-off extended runs: SPEC_FUZZ_EXTRA_SEEDS=60 python -m pytest tests/test_gpu_fuzz.py -m gpu   (60 further seeds per test)
+EXTRA_SEEDS = list(range(100, 100 + int(__import__("os").environ.get("SPEC_FUZZ_EXTRA_SEEDS", "0"))))
 DTYPES = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "cf64_be"]
 
 
@@ -31,7 +33,7 @@ def _cases(seed, n):
         yield dt, nfft, hop, n_lines, extra, start, window, fmt, on_device, lpw, int(rng.integers(1, 1 << 30))
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3] + EXTRA_SEEDS)
 def test_random_requests_match_oracle(svc, oracle, seed):
     import torch
     for dt, nfft, hop, n_lines, extra, start, window, fmt, on_device, lpw, s in _cases(seed, 60):
@@ -81,7 +83,7 @@ def _burst_cases(seed, n):
         yield dt, start, count, down, fast, f_off, alpha, on_device, int(rng.integers(1, 1 << 30))
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [11, 12] + EXTRA_SEEDS)
 def test_random_burst_requests_match_oracle(svc, oracle, seed):
     """The burst chain (EDC:54-117, ADC:219-284) end to end on random requests: reader bit-exact, down-converter
     and traces within the fp64 tolerances of tests/test_gpu_burst.py, host and device residency."""
@@ -124,7 +126,7 @@ def _welch_cases(seed, n):
                int(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(1, 1 << 30)))
 
 
-@pytest.mark.parametrize("seed", [4, 5, 6])
+@pytest.mark.parametrize("seed", [4, 5, 6] + EXTRA_SEEDS)
 def test_random_welch_requests_match_oracle(svc, oracle, seed):
     """The Welch entry (ADC:303-313 call shape, batched) over random datatype / nfft / hop / segments / batch / start /
     window / scaling, host or device input: linear within 5e-6 of the PSD's peak (fp32 sums; 1e-9 for the fp64 family that
@@ -154,7 +156,7 @@ def test_random_welch_requests_match_oracle(svc, oracle, seed):
             assert np.abs(res[1][b] - ref_db)[strong].max() <= 2e-3, tag
 
 
-@pytest.mark.parametrize("seed", [10, 11])
+@pytest.mark.parametrize("seed", [10, 11] + EXTRA_SEEDS)
 def test_random_redraws_match_the_restated_renderer(svc, oracle, seed):
     """One redraw (MC:980-999 lines, MC:1261-1291 image) on random requests: the fused form (compact tile) gives the very
     pixels of the two-pass form, and both are the restated Java renderer applied to the GPU's own dB tile -- any datatype,
@@ -184,7 +186,7 @@ def test_random_redraws_match_the_restated_renderer(svc, oracle, seed):
         assert np.array_equal(fused, oracle.render_spectrogram(tile.astype(np.float64), height, fs, lo, hi, cmap)), tag
 
 
-@pytest.mark.parametrize("seed", [12, 13])
+@pytest.mark.parametrize("seed", [12, 13] + EXTRA_SEEDS)
 def test_random_sharded_requests_equal_the_single_context_tile(svc, oracle, seed):
     """spec_waterfall_multi over one to four contexts (all on device 0 on the one-GPU box) on random requests -- datatype, size,
     hop, start, line count (also fewer lines than contexts), lines past the end, window, output format, host or device tile,
@@ -232,7 +234,7 @@ def test_random_sharded_requests_equal_the_single_context_tile(svc, oracle, seed
             p.close()
 
 
-@pytest.mark.parametrize("seed", [16, 17])
+@pytest.mark.parametrize("seed", [16, 17] + EXTRA_SEEDS)
 def test_random_psd_dialog_calls_match_scipy(svc, seed):
     """calculatePsdWelch(double[2][N], fs, nfft) (ADC:303-313) on random bursts: nfft = the burst length for short bursts (the
     dialog's rule, any integer) or any length up to 8192, explicit hop; against scipy.signal.welch -- an oracle that shares no
