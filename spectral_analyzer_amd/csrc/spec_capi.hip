@@ -1638,6 +1638,7 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         if (st != SPEC_OK) return st;
         st = get_window(c, log2n, true, window, &a.win, &s1, &s2, /*table_for_rect=*/true);
         if (st != SPEC_OK) return st;
+        a.win_hann = window == SPEC_WIN_HANN ? 1 : 2;
         const uint32_t sub = (uint32_t)v3d_lpw(log2n);
         uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg
                                                 : ((uint64_t)n_seg * n_psd) / ((uint64_t)c->n_cu * 8 * sub);

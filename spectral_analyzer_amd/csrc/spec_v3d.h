@@ -18,6 +18,9 @@ namespace {
 #ifndef SPEC_V3D_LDS_TWL
 #define SPEC_V3D_LDS_TWL 1
 #endif
+#ifndef SPEC_V3D_WIN_COMPUTED
+#define SPEC_V3D_WIN_COMPUTED 1
+#endif
 #ifndef SPEC_V3D_PREFETCH_ALL
 #define SPEC_V3D_PREFETCH_ALL 1
 #endif
@@ -102,7 +105,19 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
         for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
     }
     const double *win = static_cast<const double *>(a.win);
-    if constexpr (PL::NPASS > 2 || MODE == 0 || LDS_TWL) __syncthreads();
+    // Round 4: the Hann window computed, not read (as spec_k_v3h.hip): w[n] = 1/2 - 1/2 Re(W_N^t W_16^m) for n = t + m T, from the
+    // thread's W_N^t and sixteen W_16^m in LDS -- three fp64 operations per sample instead of a load from L2 whose latency every
+    // line waited out (+3 ... +18 %, profiles/r04_fp64_window.txt).  Any other table (the ones of a rectangular Welch) is read.
+    v2d *w16 = reinterpret_cast<v2d *>(smem + p2_lds_bytes<L, 16>() + (MODE == 0 ? DB20_TAB_DOUBLES * sizeof(double) : 0) + V3dTw<L>::BYTES);
+    const bool hann = HAS_WIN && SPEC_V3D_WIN_COMPUTED != 0 && a.win_hann == 1;
+    v2d wt = v2d{1.0, 0.0};
+    if constexpr (HAS_WIN) {
+        if (hann) {
+            if (tid < 16) w16[tid] = tw[tid * T];
+            wt = tw[t];
+        }
+    }
+    if constexpr (PL::NPASS > 2 || MODE == 0 || LDS_TWL || HAS_WIN) __syncthreads();
 
     const uint32_t unit = blockIdx.x / a.wgs_per_unit, wg = blockIdx.x % a.wgs_per_unit;
     const uint32_t line0 = wg * (uint32_t)PL::LPW * a.run;
@@ -154,10 +169,20 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
 #pragma unroll
         for (int m = 0; m < E; ++m) v[m] = RW::template dec<v2d>(BE ? RW::swap(raw[m]) : raw[m]);  // SMH:87-91
         if constexpr (HAS_WIN) {
-            const double *wp = win;
-            asm volatile("" : "+s"(wp));  // window values are re-read every line (no registers to keep them)
+            if (hann) {
 #pragma unroll
-            for (int m = 0; m < E; ++m) { const double w = wp[t + m * T]; v[m] *= v2d{w, w}; }
+                for (int m = 0; m < E; ++m) {
+                    const v2d cs = w16[m];
+                    const double c = __builtin_fma(wt.x, cs.x, -(wt.y * cs.y));
+                    const double w = __builtin_fma(-0.5, c, 0.5);
+                    v[m] *= v2d{w, w};
+                }
+            } else {
+                const double *wp = win;
+                asm volatile("" : "+s"(wp));  // window values are re-read every line (no registers to keep them)
+#pragma unroll
+                for (int m = 0; m < E; ++m) { const double w = wp[t + m * T]; v[m] *= v2d{w, w}; }
+            }
         }
         if constexpr (PREFETCH) {
             if constexpr (SH > 0 && SH < E) {
@@ -219,7 +244,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, 2) void v3d_kernel(const V2Args a) {
 template <int L, int KIND, int SH, bool HAS_WIN, bool BE = false, int MODE = 0>
 hipError_t v3d_launch1(const V2Args &a, hipStream_t s) {
     using PL = Plan2<L>;
-    constexpr size_t lds = p2_lds_bytes<L, 16>() + (MODE == 0 ? DB20_TAB_DOUBLES * sizeof(double) : 0) + V3dTw<L>::BYTES;
+    constexpr size_t lds = p2_lds_bytes<L, 16>() + (MODE == 0 ? DB20_TAB_DOUBLES * sizeof(double) : 0) + V3dTw<L>::BYTES + (HAS_WIN ? 16 * sizeof(v2d) : 0);
     static_assert(lds <= 160 * 1024, "one workgroup's LDS");
     auto kern = v3d_kernel<L, KIND, SH, HAS_WIN, BE, MODE>;
     if (lds > 64 * 1024) {
