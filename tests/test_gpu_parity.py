@@ -18,8 +18,12 @@ test_cm3_transform_own_error_per_length).  The GPU pipeline uses exact twiddles 
 the fp32 bound scaled by eps64 / eps32 plus what a dB value good to 3e-13 dB can carry), so what the comparison can hold is
     * every bin with |X| >= 1e-9 M:  | |X|_gpu - |X|_ref |  <=  max(OWN(N), REF(N)) M         (fp64_tol)
       (REF takes over from 4096 points on: 1.6e-13 at 4096, 2.6e-12 at 65536)
-    * bins with |X| >= 1e-5 M:       | dB_gpu - dB_ref |    <=  max(1e-9, 1e-12 N) dB          (fp64_db_tol)
-      (measured reference-vs-exact: 1.8e-10 dB at 4096, 1.3e-9 at 8192, 1.2e-8 at 65536)
+    * bins with |X| >= 1e-5 M:       | dB_gpu - dB_ref |    <=  max(1e-9, 3e-12 N) dB          (fp64_db_tol)
+      (measured reference-vs-exact, typical: 1.8e-10 dB at 4096, 1.3e-9 at 8192, 1.2e-8 at 65536.  Rounds 3-4 stated 1e-12 N;
+      round 4's extended random runs -- ~3000 fp64 requests -- found two lines beyond it, 4.6e-9 dB at 4096 points and 2.5e-8 at
+      16384 = 1.1 / 1.5e-12 N, and tools/err_v3h.py shows whose error that is: against a long-double DFT the oracle is off by
+      3.2e-14 M and 1.1e-9 dB on such bins, the GPU kernels by 6e-17 M and 2e-12 dB.  Restated with a factor 2 over the worst seen;
+      test_fp64_lines_against_a_long_double_dft below holds the GPU side to the exact transform, reference-independent.)
   Up to 2048 points this is the round-2 statement (1e-9 dB); beyond, the 1e-9 dB of rounds 1-2 was a statement about the
   builder's exact-twiddle oracle, not about the Java reference, and is withdrawn.  SURVEY 8(c)'s "1e-9 dB down to 1e-9 M"
   cannot hold against any fp64 transform (an absolute error of a few 1e-16 M on a bin of 1e-6 M is already 1e-9 dB).
@@ -54,7 +58,7 @@ def fp64_tol(nfft):
 
 def fp64_db_tol(nfft):
     """dB tolerance on bins >= 1e-5 M."""
-    return max(1e-9, 1e-12 * nfft)
+    return max(1e-9, 3e-12 * nfft)
 
 
 def fp64_pow_tol(nfft):
@@ -161,6 +165,33 @@ def test_fp64_family_all_variants(svc, oracle, nfft, datatype, hop_div, window):
     if datatype.startswith("cf64"):   # fp64 arithmetic, fp32 storage
         f32 = svc.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop, window=window, out_fmt=sa.OUT_DB20_F32)
         assert f32.dtype == np.float32 and np.abs(f32 - got[:-1]).max() <= 2e-5
+
+
+# ---- the fp64 pipeline against the EXACT transform (no oracle, no reference in between) ---------------------------------
+@pytest.mark.parametrize("nfft", [1024, 4096, 8192, 16384, 65536])
+@pytest.mark.parametrize("datatype", ["cf64_le", "cf32_le"])
+def test_fp64_lines_against_a_long_double_dft(svc, oracle, nfft, datatype):
+    """Every fp64 kernel of the dispatch (family, 8192-point plan with LDS twiddles, single-workgroup 16384-point kernel, team /
+    two-launch four-step at 65536) against a DFT evaluated in long double for 192 bins of one line (the strongest, the weakest
+    above 1e-5 M, and a stride through the rest): | |X|_gpu - |X|_exact | <= 1e-15 M on every one of them, |dB| <= 1e-10 on those
+    >= 1e-5 M.  The parity tolerances above are wider only because the REFERENCE's transform is (its twiddle recurrence)."""
+    iq = oracle.synth_iq(datatype, seed=nfft // 512 + 3, first_sample=0, n_samples=nfft)
+    x = (iq.view(np.float32) if datatype == "cf32_le" else iq.view(np.float64)).astype(np.longdouble).reshape(-1, 2)
+    xc = x[:, 0] + 1j * x[:, 1]
+    p = svc.compute_waterfall(iq, 0, nfft, datatype, 1, hop=nfft, out_fmt=sa.OUT_POW_F64)[0]
+    mag = np.sqrt(p)
+    M = mag.max()
+    order = np.argsort(mag)
+    weak = order[np.searchsorted(mag[order], 1e-5 * M):][:32]            # the weakest bins the dB statement covers
+    cols = np.unique(np.concatenate([order[-32:], weak, np.arange(0, nfft, nfft // 128)]))
+    k = ((cols - nfft // 2) % nfft).astype(np.longdouble)[:, None]       # column c holds bin (c - N/2) mod N   (SS:78)
+    n = np.arange(nfft, dtype=np.longdouble)[None, :]
+    two_pi = 2 * np.longdouble("3.14159265358979323846264338327950288")
+    X = (np.exp(-1j * (two_pi * ((k * n) % nfft) / nfft)) * xc[None, :]).sum(axis=1)
+    exact = np.abs(X).astype(np.float64)
+    assert np.abs(mag[cols] - exact).max() <= 1e-15 * M, np.abs(mag[cols] - exact).max() / M
+    sel = exact >= 1e-5 * M
+    assert np.abs(20 * np.log10(mag[cols][sel]) - 20 * np.log10(exact[sel])).max() <= 1e-10
 
 
 # ---- values at the edges of fp32: overflow of |X|^2, underflow, NaN -------------------------------------
