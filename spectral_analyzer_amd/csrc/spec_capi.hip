@@ -595,6 +595,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         const void *tw_half = nullptr;
         if ((st = get_twiddles(c, log2n, false, &a.tw)) != SPEC_OK) return st;
         if ((st = get_twiddles(c, log2n - 1, false, &tw_half)) != SPEC_OK) return st;
+        const void *tw_full64 = nullptr;  // the window's cosine is formed in fp64
+        if (a.win && (st = get_twiddles(c, log2n, true, &tw_full64)) != SPEC_OK) return st;
         uint64_t done = 0;
         while (done < n_lines) {
             const uint64_t rem = n_lines - done;
@@ -608,7 +610,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             a.n_lines = rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull;
             a.iq = d_first + done * (uint64_t)hop * a.bps;
             a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
-            hipError_t e = launch_v2h_spectro(a, log2n, tw_half, (uint32_t)run, c->stream);
+            hipError_t e = launch_v2h_spectro(a, log2n, tw_half, tw_full64, (uint32_t)run, c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "32768-point launch: %s", hipGetErrorString(e));
             done += a.n_lines;
         }

@@ -89,7 +89,7 @@ hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t 
 // 32768- (and, as an option, 16384-) point fp32 lines in one workgroup (spec_k_v2h.hip): w.tw = v2f W_N table, tw_half = v2f
 // W_(N/2) table, w.win = non-null for the Hann window; `run` consecutive lines per workgroup
 bool v2h_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop);
-hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, uint32_t run, hipStream_t s);
+hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, const void *tw_full64, uint32_t run, hipStream_t s);  // tw_full64: v2d W_N table, needed with a window
 // 16384-point fp64 lines in one workgroup (spec_k_v3h.hip): w.tw = v2d W_16384 table, tw_half = v2d W_8192 table
 bool v3h_applicable(int log2n, int kind, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v3h_spectro(const WfArgs &w, const void *tw_half, uint32_t run, hipStream_t s);

@@ -30,6 +30,7 @@ struct V2hArgs {
     uint32_t n_lines, hop, run;  // run: consecutive lines per workgroup
     const void *tw_half;   // v2f W_16384^m
     const void *tw_full;   // v2f W_32768^m
+    const void *tw_full64; // v2d W_N^m: the Hann window's cosine is formed in fp64 (non-null with `win`)
     const void *win;       // non-null: Hann window (computed from the twiddles, the table is not read)
     float *out;
     int out_fmt;
@@ -173,8 +174,12 @@ __global__ __launch_bounds__(Plan2<L>::T, L == 12 ? V2H_WAVES_12 : 2) void v2h_k
     const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw_half);
 
     fill_tables<L, 1>(tab, tw, t);
-    v2f *wtab = tab + p2_tab_entries<L>();  // W_64^m = W_N^(512 m), m < 32 (the Hann window's cosine, below)
-    if (HAS_WIN && t < E) wtab[t] = static_cast<const v2f *>(a.tw_full)[T * t];
+    v2d *wtab = reinterpret_cast<v2d *>(tab + p2_tab_entries<L>());  // W_NT^m = W_N^(T m), m < E, in fp64 (the Hann window's cosine, below)
+    v2d *wt64s = wtab + 32;  // W_N^t of every thread, in LDS: four registers only while a line is decoded
+    if constexpr (HAS_WIN) {
+        if (t < E) wtab[t] = static_cast<const v2d *>(a.tw_full64)[T * t];
+        wt64s[t] = static_cast<const v2d *>(a.tw_full64)[t];
+    }
     v2f twl[16];
 #pragma unroll
     for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (H - 1)];
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(Plan2<L>::T, L == 12 ? V2H_WAVES_12 : 2) void v2h_k
         const int next_off = (int)((line + 1) * line_bytes);
         v2f v[E], dd[PARK_RAW ? 1 : E];
         (void)dd;
-        auto decode = [&](int m, v2f &lo, v2f &hi) {
+        auto decode = [&](int m, v2f &lo, v2f &hi, v2d wt64) {
             lo = RW::dec(BE ? RW::swap(rlo[m]) : rlo[m]);  // SMH:87-91 byte order
             hi = RW::dec(BE ? RW::swap(rhi[m]) : rhi[m]);
             if constexpr (HAS_WIN) {
@@ -219,18 +224,23 @@ __global__ __launch_bounds__(Plan2<L>::T, L == 12 ? V2H_WAVES_12 : 2) void v2h_k
                 // Re(W_N^t W_64^m) for n = t + 512 m -- from the twiddle the thread holds and W_64^m (a 32-entry LDS table), where the
                 // table cost two loads per sample from L2 for each half (0.32 of 8 TB/s against 0.43 without a window);
                 // n + H turns the cosine's sign.  (`win` only says that a window is wanted.)
-                const v2f cs = wtab[m];  // W_64^m from LDS (one broadcast read): as 64 literals the compiler pins them in registers
-                const float c = __builtin_fmaf(wt.x, cs.x, -(wt.y * cs.y));
-                const float w0 = __builtin_fmaf(-0.5f, c, 0.5f), w1 = __builtin_fmaf(0.5f, c, 0.5f);
+                // The cosine in fp64 (round 4, after the extended random runs): formed from the fp32 twiddles its error, ~1.5e-7 and
+                // the same for all of a thread's samples, reached the tolerance of the 1e-4 M tier (5.4e-3 dB seen at 16384 points
+                // against 3.0e-3 with the table, tools/err_window.py); now the window is the table's value to fp32 rounding.
+                const v2d cs = wtab[m];  // one broadcast LDS read
+                const double c = __builtin_fma(wt64.x, cs.x, -(wt64.y * cs.y));
+                const float w0 = (float)__builtin_fma(-0.5, c, 0.5), w1 = (float)__builtin_fma(0.5, c, 0.5);
                 lo *= v2f{w0, w0};
                 hi *= v2f{w1, w1};
             }
         };
         // ---- first radix-2 step, even half: a = lo + hi ----
+        v2d wt64 = v2d{1.0, 0.0};
+        if constexpr (HAS_WIN) wt64 = wt64s[t];
 #pragma unroll
         for (int m = 0; m < E; ++m) {
             v2f lo, hi;
-            decode(m, lo, hi);
+            decode(m, lo, hi, wt64);
             v[m] = lo + hi;
             if constexpr (!PARK_RAW) {
                 dd[m] = lo - hi;
@@ -245,6 +255,7 @@ __global__ __launch_bounds__(Plan2<L>::T, L == 12 ? V2H_WAVES_12 : 2) void v2h_k
         v2h_epilogue<BOUNDED, E>(v, RW::SCALE, db, de);
 
         // ---- odd half: b = (lo - hi) W_N^(t + 512 m) = d W_64^m W_N^t ----
+        if constexpr (HAS_WIN && PARK_RAW) wt64 = wt64s[t];  // (read again: not kept across the transform)
         v2h_for_each([&](auto mt) {
             constexpr int m = decltype(mt)::value;
             if constexpr (PARK_RAW) {
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(Plan2<L>::T, L == 12 ? V2H_WAVES_12 : 2) void v2h_k
                 // decoded a second time from the parked raw registers; the empty asm keeps hipcc from re-using the first
                 // decode's floats instead (128 registers alive across the first transform)
                 asm volatile("" : "+v"(rlo[m]), "+v"(rhi[m]));
-                decode(m, lo, hi);
+                decode(m, lo, hi, wt64);
                 v[m] = v2h_twiddle<m, NT>(lo - hi, wt);
             } else {
                 v[m] = v2h_twiddle<m, NT>(dd[m], wt);
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(Plan2<L>::T, L == 12 ? V2H_WAVES_12 : 2) void v2h_k
 }
 
 template <int L, int KIND, bool HAS_WIN, bool BE, bool REUSE> hipError_t v2h_launch1(const V2hArgs &a, hipStream_t s) {
-    constexpr size_t lds = p2_lds_bytes<L>() + 32 * sizeof(v2f);  // + the W_64 table of the window
+    constexpr size_t lds = p2_lds_bytes<L>() + (32 + (HAS_WIN ? Plan2<L>::T : 0)) * sizeof(v2d);  // + the window's W_NT table and per-thread W_N^t (fp64)
+    static_assert(lds <= 160 * 1024, "one workgroup's LDS");
     auto kern = v2h_kernel<L, KIND, HAS_WIN, BE, REUSE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -326,10 +338,10 @@ bool v2h_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t
     return n_lines > 0 && n_lines < (1ull << 31) && hop <= (8u << log2n);  // a workgroup's span stays far below 4 GiB
 }
 
-hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, uint32_t run, hipStream_t s) {
+hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, const void *tw_full64, uint32_t run, hipStream_t s) {
     V2hArgs a{};
     a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.run = run;
-    a.tw_half = tw_half; a.tw_full = w.tw; a.win = w.win;
+    a.tw_half = tw_half; a.tw_full = w.tw; a.tw_full64 = tw_full64; a.win = tw_full64 ? w.win : nullptr;
     a.out = static_cast<float *>(w.out); a.out_fmt = w.out_fmt;
     return log2n == 15 ? v2h_launch_l<14>(a, w.kind, w.be, s) : log2n == 14 ? v2h_launch_l<13>(a, w.kind, w.be, s) : v2h_launch_l<12>(a, w.kind, w.be, s);
 }
