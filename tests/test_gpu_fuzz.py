@@ -8,8 +8,9 @@ import spectral_analyzer_amd as sa
 from test_gpu_parity import check_fp32, check_fp64
 
 pytestmark = pytest.mark.gpu
-# one-off extended runs: SPEC_FUZZ_EXTRA_SEEDS=60 python -m pytest tests/test_gpu_fuzz.py -m gpu   (60 further seeds per test)
-EXTRA_SEEDS = list(range(100, 100 + int(__import__("os").environ.get("SPEC_FUZZ_EXTRA_SEEDS", "0"))))
+# one-off extended runs: SPEC_FUZZ_EXTRA_SEEDS=60 [SPEC_FUZZ_SEED_BASE=100] python -m pytest tests/test_gpu_fuzz.py -m gpu   (60 further seeds per test)
+_BASE = int(__import__("os").environ.get("SPEC_FUZZ_SEED_BASE", "100"))
+EXTRA_SEEDS = list(range(_BASE, _BASE + int(__import__("os").environ.get("SPEC_FUZZ_EXTRA_SEEDS", "0"))))
 DTYPES = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "cf64_be"]
 
 
