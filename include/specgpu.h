@@ -149,7 +149,7 @@ void *spec_stream(const spec_ctx *ctx);
  *   "mid_single" = 2 | 1 | 0   16384-point fp32 lines through the same half-line kernel (256-thread workgroups, two per CU):
  *                     2 (default) = where it was measured faster than the family's kernel (without a window: everything but
  *                     cf32 at 75 % / 50 % overlap and ci16 at 75 %, where the family keeps the overlap in registers; with the
- *                     Hann window: big-endian files and cf32 at hops other than N/4, N/2, N), 1 = always, 0 = never
+ *                     Hann window: big-endian files only), 1 = always, 0 = never
  *   "small_single" = 2 | 1 | 0   8192-point fp32 lines through it (16 points per thread and half, three workgroups per CU):
  *                     2 (default) = cf32 where the family's kernel has no register-reuse variant (big-endian files, hops other
  *                     than N/4, N/2, N; 8 ... 11 points of the roofline faster; level everywhere else), 1 = always, 0 = never

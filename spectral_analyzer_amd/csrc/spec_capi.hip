@@ -566,7 +566,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     // measured case by case (tools/bench_mid.py, profiles/r04_mid.txt; re-measured after the family's 32-point threads got their
     // Hann window from LDS, which turned every windowed case but two its way).  "mid_single" = 2 (default) that rule, 1 always, 0 never:
     //   big-endian cf32 / ci16: half-line below hop = N (the family has one variant without register reuse: 0.32-0.42 vs 0.36-0.46)
-    //   with a window: the family, except cf32 at hops other than N/4, N/2, N (0.49 vs 0.51)
+    //   with a window: the family (the half-line kernel's computed window has its cosine in fp64 since the accuracy runs of round 4: 0.47 vs 0.50)
     //   without: cf32 half-line at hops other than N/4, N/2 (the family keeps the overlap in registers there: 0.43 / 0.52 vs 0.37 / 0.48);
     //            ci16 half-line except at N/4; cu8 / ci8 half-line (+1 ... 2 points)
     bool mid_single = false;
@@ -574,7 +574,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         const bool reuse_hop = hop == nfft / 4 || hop == nfft / 2;
         bool half;
         if (a.be && (a.kind == K_CF32 || a.kind == K_CI16)) half = hop != nfft;
-        else if (window != SPEC_WIN_RECT) half = a.kind == K_CF32 && !reuse_hop && hop != nfft;
+        else if (window != SPEC_WIN_RECT) half = false;
         else if (a.kind == K_CF32) half = !reuse_hop;
         else if (a.kind == K_CI16) half = hop != nfft / 4;
         else half = true;
