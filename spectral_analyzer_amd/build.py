@@ -55,45 +55,55 @@ def _stamp(extra) -> str:
 
 # named variants: what they are compiled with, and which translation units the flags touch (the others are taken from
 # the product build as they are)
-VARIANTS = {
+def _unique(pairs):
+    """dict(pairs), refusing a name defined twice (round 4 lost a variant that way)"""
+    out = {}
+    for name, spec in pairs:
+        if name in out:
+            raise ValueError("build variant %r is defined twice" % name)
+        out[name] = spec
+    return out
+
+
+VARIANTS = _unique([
     # the team kernel's two experiment geometries (large_wg = 256 / 1024): measured slower (DESIGN.md 4.4), kept
     # under test (tests/test_gpu_large.py), not carried by the product library
-    "teamvar": (["-DSPEC_TEAM_VARIANTS"], ["spec_k_team.hip"]),
+    ("teamvar", (["-DSPEC_TEAM_VARIANTS"], ["spec_k_team.hip"])),
     # development aid: lane-0 cycle counters inside the team kernel (tools/team_prof.py)
-    "tPROF": (["-DSPEC_TEAM_PROF"], ["spec_k_team.hip", "spec_capi.hip"]),
+    ("tPROF", (["-DSPEC_TEAM_PROF"], ["spec_k_team.hip", "spec_capi.hip"])),
     # experiments on the single-workgroup 32768-point kernel: how many cf32 samples of the next line are requested
     # beside the second transform (tools/bench_v2h.py)
     # round-4 experiment: wave-autonomous sides of the team kernel (fp64 lines)
-    "tWA": (["-DSPEC_TEAM_WA"], ["spec_k_team.hip"]),
-    "tWAnt": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_LD=0"], ["spec_k_team.hip"]),
+    ("tWA", (["-DSPEC_TEAM_WA"], ["spec_k_team.hip"])),
+    ("tWAnt", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_LD=0"], ["spec_k_team.hip"])),
     # ablations of it (results wrong by construction): column side alone; without its slot stores; without its arithmetic
-    "tWAa": (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
-    "tWAb": (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT"], ["spec_k_team.hip"]),
-    "tWAc": (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT", "-DSPEC_ABL_TEAM_NOFFT"], ["spec_k_team.hip"]),
-    "tWAs": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0"], ["spec_k_team.hip"]),
-    "tWA1": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=1"], ["spec_k_team.hip"]),
-    "tWA2": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2"], ["spec_k_team.hip"]),
-    "tWA1a": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=1", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
-    "tWA2a": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
-    "tWAca": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
-    "tWAcb": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT"], ["spec_k_team.hip"]),
-    "tWAsa": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
-    "tWAc": (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED"], ["spec_k_team.hip"]),
-    "tOLDa": (["-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"]),
-    "v2hpf0": (["-DV2H_PF=0"], ["spec_k_v2h.hip"]),
-    "v2hpf8": (["-DV2H_PF=8"], ["spec_k_v2h.hip"]),
-    "v2hpf20": (["-DV2H_PF=20"], ["spec_k_v2h.hip"]),
-    "v2hw4": (["-DV2H_WAVES_12=4"], ["spec_k_v2h.hip"]),
-    "v2hw2": (["-DV2H_WAVES_12=2"], ["spec_k_v2h.hip"]),
+    ("tWAa", (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"])),
+    ("tWAb", (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT"], ["spec_k_team.hip"])),
+    ("tWAnf", (["-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT", "-DSPEC_ABL_TEAM_NOFFT"], ["spec_k_team.hip"])),
+    ("tWAs", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0"], ["spec_k_team.hip"])),
+    ("tWA1", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=1"], ["spec_k_team.hip"])),
+    ("tWA2", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2"], ["spec_k_team.hip"])),
+    ("tWA1a", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=1", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"])),
+    ("tWA2a", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_ANN=2", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"])),
+    ("tWAca", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"])),
+    ("tWAcb", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT", "-DSPEC_ABL_TEAM_NOSLOT"], ["spec_k_team.hip"])),
+    ("tWAsa", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"])),
+    ("tWAc", (["-DSPEC_TEAM_WA", "-DSPEC_TEAM_WA_DEEP=0", "-DSPEC_ABL_WA_COALESCED"], ["spec_k_team.hip"])),
+    ("tOLDa", (["-DSPEC_ABL_TEAM_NOB", "-DSPEC_ABL_TEAM_NOWAIT"], ["spec_k_team.hip"])),
+    ("v2hpf0", (["-DV2H_PF=0"], ["spec_k_v2h.hip"])),
+    ("v2hpf8", (["-DV2H_PF=8"], ["spec_k_v2h.hip"])),
+    ("v2hpf20", (["-DV2H_PF=20"], ["spec_k_v2h.hip"])),
+    ("v2hw4", (["-DV2H_WAVES_12=4"], ["spec_k_v2h.hip"])),
+    ("v2hw2", (["-DV2H_WAVES_12=2"], ["spec_k_v2h.hip"])),
     # fp64 family: last-pass twiddles in registers (rounds 1-3) / in LDS without the cf64 / cf32 prefetch
-    "v3dreg": (["-DSPEC_V3D_LDS_TWL=0"], ["spec_k_v3d.hip"]),
-    "v3dnp": (["-DSPEC_V3D_PREFETCH_ALL=0"], ["spec_k_v3d.hip"]),
+    ("v3dreg", (["-DSPEC_V3D_LDS_TWL=0"], ["spec_k_v3d.hip"])),
+    ("v3dnp", (["-DSPEC_V3D_PREFETCH_ALL=0"], ["spec_k_v3d.hip"])),
     # 32-point-per-thread plans: the window re-read from the L2-resident table every line (rounds 1-3) instead of a quarter Hann table in LDS
-    "v2wg": (["-DSPEC_V2_WIN_LDS=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip"]),
-    "v3hhi": (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"]),
-    "v3he48": (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"]),
-    "v3he64": (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"]),
-}
+    ("v2wg", (["-DSPEC_V2_WIN_LDS=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip"])),
+    ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),
+    ("v3he48", (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"])),
+    ("v3he64", (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"])),
+])
 
 
 def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=(), only=None) -> str:

@@ -79,6 +79,7 @@ struct spec_ctx {
     int64_t opt_small_single = 2;  // 8192-point fp32 lines through the same kernel (16 points per thread and half): 2 where measured faster, 1 always, 0 never
     int64_t opt_mid_single = 2;    // 16384-point fp32 lines through the same kernel: 2 where measured faster (run_lines), 1 always, 0 never
     int64_t opt_welch_two_pass = 0;
+    int64_t opt_welch_rows = 1;  // 16384-point Welch segments: the plan whose second exchange stays inside half a wave (spec_v2.h Plan2<214>); 0: 32 x 32 x 16
     // the persistent large-N kernel: a launch whose abort word has not been looked at yet, and the verdict once a
     // bounded wait did time out on this context (shared / partitioned GPU): it is not tried again
     bool team_check_pending = false, team_disabled = false;
@@ -361,6 +362,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "rec_pread")) c->opt_rec_pread = value != 0;
     else if (!strcmp(key, "welch_two_pass")) c->opt_welch_two_pass = value != 0;
+    else if (!strcmp(key, "welch_rows")) c->opt_welch_rows = value != 0;
     else if (!strcmp(key, "large_team")) {
         c->opt_large_team = value < 0 ? 0 : (value > 3 ? 3 : value);
         c->team_disabled = false;  // setting the knob gives the persistent launch another chance
@@ -387,7 +389,7 @@ spec_status spec_get_option(spec_ctx *c, const char *key, int64_t *value) {
     if (!key || !value) return fail(c, SPEC_EINVAL, "spec_get_option: null argument");
     struct { const char *k; int64_t v; } tab[] = {
         {"force_generic", c->opt_force_generic}, {"lines_per_wg", c->opt_lines_per_wg}, {"large_chunk_mb", c->opt_large_chunk_mb},
-        {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass},
+        {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass}, {"welch_rows", c->opt_welch_rows},
         {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"mid_single", c->opt_mid_single}, {"small_single", c->opt_small_single},
         {"large_block", c->opt_large_block}, {"render_fused", c->opt_render_fused}, {"readahead_lines", c->opt_readahead_lines},
         {"large_team_fake_abort", c->opt_team_fake_abort}, {"large_team_disabled", c->team_disabled ? 1 : 0},
@@ -1617,6 +1619,7 @@ static spec_status welch_impl(spec_ctx *c, const void *iq, int iq_on_device, uin
         a.final_out = fused ? d_out : nullptr;
         a.norm = norm;
         a.db = db;
+        a.rows = (int)c->opt_welch_rows;
         hipError_t e = launch_v2_welch(a, log2n, (uint32_t)run, wgs, c->stream);
         if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "welch launch: %s", hipGetErrorString(e));
         if (!fused) {

@@ -58,6 +58,23 @@ template <> struct Plan2<113> {
     static constexpr int LINE = N + (N >> PADSH);
 };
 
+// Plan id 214 (round 5): 16384 points as 16 x (32 x 32) -- ONE workgroup-wide radix-16 step (decimation in frequency: the
+// twiddles W_N^(i r) follow the butterfly), then sixteen 1024-point rows, each owned by the 32 lanes of half a wave, whose
+// single exchange stays inside that half wave (no s_barrier; a wave's DS operations complete in order).  Two barriers
+// per line instead of four, the same arithmetic in another order.  A row's thread ends up with the bins
+// g + 16 l + 512 m (g = row, l = lane of the row): consecutive lanes are sixteen bins apart, so the plan serves the
+// kernels that do not store a line per transform -- the Welch sums (MODE 1) -- and nothing else.
+template <> struct Plan2<214> {
+    static constexpr int E = 32, N = 16384, T = N / E, NPASS = 3;
+    static constexpr int radix[4] = {16, 32, 32, 1};
+    static constexpr int WG = T, LPW = 1;
+    static constexpr bool WAVE_LOCAL = false;
+    static constexpr int PADSH = 5;
+    static constexpr int ROWS = 16, ROW = 1024 + 32;  // a row's region: 1024 elements + one pad per 32 (its own exchange)
+    static constexpr int LINE = ROWS * ROW;
+};
+template <int L> constexpr bool p2_rows() { return L == 214; }
+
 template <int L> constexpr int p2_P_of(int pass) {  // product of the radices before `pass`
     int p = 1;
     for (int q = 0; q < pass; ++q) p *= Plan2<L>::radix[q];
@@ -73,7 +90,10 @@ template <int L> constexpr int p2_tab_off_of(int pass) {
     return o;
 }
 template <int L, int PASS> constexpr int p2_tab_off() { return p2_tab_off_of<L>(PASS); }
-template <int L> constexpr int p2_tab_entries() { return p2_tab_off_of<L>(Plan2<L>::NPASS - 1); }
+template <int L> constexpr int p2_tab_entries() {
+    if constexpr (p2_rows<L>()) return 1024;  // W_1024^(m l) of the rows' second pass
+    else return p2_tab_off_of<L>(Plan2<L>::NPASS - 1);
+}
 template <int L, int ELEM = 8> constexpr size_t p2_lds_bytes() {  // ELEM: bytes per complex value (8 fp32, 16 fp64)
     return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * ELEM + (size_t)p2_tab_entries<L>() * ELEM;
 }
@@ -241,7 +261,9 @@ template <int L, int PASS, typename V> __device__ __forceinline__ void v2_load(V
 // W_N^(r k STEP) for the (r, k) of one middle pass
 template <int L, int PASS, typename V> __device__ __forceinline__ void fill_tables(V *tab, const V *__restrict__ tw, int tid) {
     using PL = Plan2<L>;
-    if constexpr (PASS < PL::NPASS - 1) {
+    if constexpr (p2_rows<L>()) {  // entry (m, l) = W_1024^(m l) = W_N^(16 m l)
+        for (int e = tid; e < 1024; e += PL::WG) tab[e] = tw[((e >> 5) * (e & 31) * 16) & (PL::N - 1)];
+    } else if constexpr (PASS < PL::NPASS - 1) {
         constexpr int P = p2_P<L, PASS>(), R = PL::radix[PASS], STEP = PL::N / (P * R);
         for (int e = tid; e < R * P; e += PL::WG) {
             const V w0 = tw[(e / P) * (e % P) * STEP];
@@ -263,26 +285,122 @@ template <int L> __device__ __forceinline__ void v2_sync() {
     }
 }
 
-template <int L, int PASS = 0, typename V>
-__device__ __forceinline__ void v2_fft(V (&v)[Plan2<L>::E], int t, V *lds, const V *tab, V (&twl)[16]) {
-    using PL = Plan2<L>;
-    // SPEC_ABL_*: ablation builds of tools/ablate.sh (one stage removed, results wrong by construction,
-    // DESIGN.md 4.7); never defined in a product build
-#ifndef SPEC_ABL_NOFFT
-    v2_pass<L, PASS>(v, t, tab, twl);
+// Development aid (-DSPEC_V2_STAMPS, build.py --variant v2stamp; tools/v2_timeline.py): lane 0 of every wave notes the shader
+// clock at the phase boundaries of a line in LDS words of its own; never defined in a product build
+#ifdef SPEC_V2_STAMPS
+#define V2_STAMP(sp, id) do { if (sp) { const uint32_t c__ = (uint32_t)__builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) (sp)[id] = c__; } } while (0)
+#else
+#define V2_STAMP(sp, id) do { (void)(sp); } while (0)
 #endif
-    if constexpr (PASS + 1 < PL::NPASS) {
+
+// Plan2<214>: see the plan.  twl[r] = W_N^(r t) as for every plan; tab = W_1024^(m l).
+template <typename V>
+__device__ __forceinline__ void v2_fft_rows(V (&v)[32], int t, V *lds, const V *tab, V (&twl)[16], uint32_t *sp) {
+    using PL = Plan2<214>;
+    constexpr int ROW = PL::ROW;
+    // pass 0: butterfly s over the registers {s + 2 r} = x[i + 1024 r], i = t + 512 s; output r times W_N^(i r) =
+    // W_N^(t r) W_32^(s r)
+#ifndef SPEC_ABL_NOFFT
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        V u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = v[s + 2 * r];
+        pk_dft16(u);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            u[r] = pk_cmul(u[r], twl[r]);
+            if (s == 1) u[r] = r == 8 ? pk_mul_mi(u[r]) : pk_cmul_const(u[r], kW32[r][0], kW32[r][1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[s + 2 * r] = u[r];
+    }
+#endif
+    V2_STAMP(sp, 2);
 #ifndef SPEC_ABL_NOLDS
 #ifndef SPEC_ABL_NOBAR
-        v2_sync<L>();  // WAR: the previous exchange has been read by everyone
+    __syncthreads();  // every row of the previous line has been read
 #endif
-        v2_store<L, PASS>(v, t, lds);
+    V2_STAMP(sp, 3);
+    {   // element i of row r at r ROW + i: a wave writes 64 consecutive elements per instruction
+        V *base = lds + t;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base[r * ROW + s * 512] = v[s + 2 * r];
+    }
+    V2_STAMP(sp, 4);
 #ifndef SPEC_ABL_NOBAR
-        v2_sync<L>();
+    __syncthreads();
 #endif
-        v2_load<L, PASS>(v, t, lds);
+    V2_STAMP(sp, 5);
+    const int l = t & 31;
+    V *row = lds + (t >> 5) * ROW;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) v[m] = row[l + 32 * m];
 #endif
-        v2_fft<L, PASS + 1>(v, t, lds, tab, twl);
+    // the row's 1024-point transform, 32 x 32 on its 32 lanes: first pass without twiddles
+#ifndef SPEC_ABL_NOFFT
+    pk_dft32(v);
+#endif
+    V2_STAMP(sp, 6);
+#ifndef SPEC_ABL_NOLDS
+    // the row's own exchange (padded: lane l writes 33-element rows): the region is read and written by the lanes of
+    // this half wave only, and a wave's DS operations complete in issue order -- a scheduling fence is all it takes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        V *b = row + l * 33;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) b[r] = v[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    V2_STAMP(sp, 7);
+#pragma unroll
+    for (int m = 0; m < 32; ++m) v[m] = row[l + 33 * m];
+#endif
+#ifndef SPEC_ABL_NOFFT
+    {   // second pass: register m times W_1024^(m l)
+        const V *tr = tab + l;
+#pragma unroll
+        for (int m = 1; m < 32; ++m) v[m] = pk_cmul(v[m], tr[32 * m]);
+    }
+    pk_dft32(v);
+#endif
+    V2_STAMP(sp, 8);
+}
+
+template <int L, int PASS = 0, typename V>
+__device__ __forceinline__ void v2_fft(V (&v)[Plan2<L>::E], int t, V *lds, const V *tab, V (&twl)[16], uint32_t *sp = nullptr) {
+    using PL = Plan2<L>;
+    if constexpr (p2_rows<L>()) {
+        v2_fft_rows(v, t, lds, tab, twl, sp);
+    } else {
+        // SPEC_ABL_*: ablation builds of tools/ablate.sh (one stage removed, results wrong by construction,
+        // DESIGN.md 4.7); never defined in a product build
+#ifndef SPEC_ABL_NOFFT
+        v2_pass<L, PASS>(v, t, tab, twl);
+#endif
+        V2_STAMP(sp, 2 + 4 * PASS);
+        if constexpr (PASS + 1 < PL::NPASS) {
+#ifndef SPEC_ABL_NOLDS
+#ifndef SPEC_ABL_NOBAR
+            v2_sync<L>();  // WAR: the previous exchange has been read by everyone
+#endif
+            V2_STAMP(sp, 3 + 4 * PASS);
+            v2_store<L, PASS>(v, t, lds);
+            V2_STAMP(sp, 4 + 4 * PASS);
+#ifndef SPEC_ABL_NOBAR
+            v2_sync<L>();
+#endif
+            V2_STAMP(sp, 5 + 4 * PASS);
+            v2_load<L, PASS>(v, t, lds);
+#endif
+            v2_fft<L, PASS + 1>(v, t, lds, tab, twl, sp);
+        }
     }
 }
 
@@ -344,6 +462,7 @@ struct V2Args {
     void *final_out;        // MODE 1, one sub-line per unit: the finished PSDs (float[n_units][N]) instead of slabs
     double norm;            //         sum -> PSD factor (WelchArgs)
     int db;                 //         10 log10(psd + 1e-20)
+    int rows;               // MODE 1, 16384 points: Plan2<214> (16 rows of 1024 points, the second exchange inside half a wave)
 };
 
 // MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums; MODE 2: spectrogram
@@ -355,8 +474,11 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     using RW = Raw2<KIND>;
     using raw_t = typename RW::type;
     constexpr int BPS = RW::BPS, N = PL::N, T = PL::T, E = PL::E;
+    static_assert(!p2_rows<L>() || MODE == 1, "the row plan leaves a thread with bins sixteen apart: Welch sums only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, t = tid % T, q = tid / T;
+    // bin of register m at the end of a transform: tb + m T (row plan: row g = t / 32, lane l = t % 32 -> g + 16 l + 512 m)
+    const int tb = p2_rows<L>() ? (t >> 5) + 16 * (t & 31) : t;
     v2f *lds = reinterpret_cast<v2f *>(smem) + (size_t)q * PL::LINE;
     v2f *tab = reinterpret_cast<v2f *>(smem + (size_t)PL::LPW * PL::LINE * 8);
     const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw);
@@ -447,8 +569,17 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     // (two copies of the loop body) instead of being moved; every other variant shifts the
     // registers down (the doubled body costs them 8-40 spilled VGPRs, more than the moves)
     constexpr bool PINGPONG = SH * 2 == E && KIND == K_CF32 && !HAS_WIN && MODE == 0;
+#ifdef SPEC_V2_STAMPS
+    // [wave][segment 0..2][16] words behind everything else in LDS; a.out_stride = first stamped segment, a.sel = where they go
+    uint32_t *const stamp0 = reinterpret_cast<uint32_t *>(smem + ((p2_lds_bytes<L>() + ((size_t)N / 4 + 1) * 4 + 15) & ~(size_t)15)) + (tid >> 6) * 48;
+#endif
     auto do_line = [&](uint32_t line, auto phase_tag) {
         constexpr int PH = PINGPONG ? decltype(phase_tag)::value : 0;  // physical register of sample m: (m + PH*SH) mod E
+        uint32_t *sp = nullptr;
+#ifdef SPEC_V2_STAMPS
+        if (MODE == 1 && line >= a.out_stride && line < a.out_stride + 3) sp = stamp0 + (line - a.out_stride) * 16;
+#endif
+        V2_STAMP(sp, 0);
         v2f v[E];
         if constexpr (HAS_WIN && !WIN_REGS) {
             if (hann_lds) {
@@ -487,7 +618,8 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
         for (int m = E - NEW; m < E; ++m)  // the next line is one phase further on
             raw[PINGPONG ? (m + (1 - PH) * SH) % E : m] = RW::template load<AUX>(src, voff, next_off + m * T * BPS);
 
-        v2_fft<L>(v, t, lds, tab, twl);
+        V2_STAMP(sp, 1);
+        v2_fft<L>(v, t, lds, tab, twl, sp);
 
         if constexpr (MODE == 1) {
             if (line < my_lines) {
@@ -495,6 +627,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
                 for (int m = 0; m < E; ++m)  // two chained FMAs per point (as a sum of pk_norm: multiply, FMA and an add)
                     acc[m] = __builtin_fmaf(v[m].x, v[m].x, __builtin_fmaf(v[m].y, v[m].y, acc[m]));
             }
+            V2_STAMP(sp, 15);
         } else {
             float d[E];
             constexpr bool BOUNDED = KIND != K_CF32;
@@ -530,6 +663,10 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     } else {
         for (uint32_t line = 0; line < iters; ++line) do_line(line, std::integral_constant<int, 0>{});
     }
+#ifdef SPEC_V2_STAMPS
+    if (MODE == 1 && a.sel && blockIdx.x < 8 && (tid & 63) < 48)
+        const_cast<int32_t *>(a.sel)[(blockIdx.x * (PL::WG / 64) + (tid >> 6)) * 48 + (tid & 63)] = (int32_t)stamp0[tid & 63];
+#endif
     if constexpr (MODE == 1) {
         constexpr float s2 = RW::SCALE * RW::SCALE;
         if constexpr (PL::LPW == 1) {
@@ -540,7 +677,7 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 #pragma unroll
                 for (int m = 0; m < E; ++m) {
                     const double v = (double)(acc[m] * s2) * a.norm;
-                    psd[(t + ((m + E / 2) & (E - 1)) * T)] = a.db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
+                    psd[(tb + ((m + E / 2) & (E - 1)) * T)] = a.db ? (float)(10.0 * log10(v + 1e-20)) : (float)v;
                 }
                 return;
             }
@@ -548,14 +685,18 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
         // one fp32 slab per sub-line (zeros for idle ones); welch_finalize_kernel sums them in order
         float *slab = static_cast<float *>(a.out) + ((uint64_t)blockIdx.x * PL::LPW + q) * N;
 #pragma unroll
-        for (int m = 0; m < E; ++m) slab[t + m * T] = acc[m] * s2;
+        for (int m = 0; m < E; ++m) slab[tb + m * T] = acc[m] * s2;
     }
 }
 
 template <int L, int KIND, int SH, bool HAS_WIN, int MODE, bool BE = false>
 hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
     using PL = Plan2<L>;
+#ifdef SPEC_V2_STAMPS
+    constexpr size_t lds = ((p2_lds_bytes<L>() + ((size_t)PL::N / 4 + 1) * 4 + 15) & ~(size_t)15) + (PL::WG / 64) * 48 * 4;
+#else
     constexpr size_t lds = p2_lds_bytes<L>() + (HAS_WIN && PL::E == 32 && SPEC_V2_WIN_LDS != 0 ? ((size_t)PL::N / 4 + 1) * sizeof(float) : 0);
+#endif
     static_assert(lds <= 160 * 1024, "one workgroup's LDS");
     // Minimum waves per SIMD asked of the register allocator, chosen so that the kernel does
     // not spill: about 104 VGPRs of FFT state + 32 (cf32) or 16 raw sample registers + 16 for a
@@ -631,7 +772,11 @@ template <int MODE> hipError_t v2_launch_n(const V2Args &a, int log2n, int kind,
     case 11: return v2_launch_kind<11, MODE>(a, kind, s);
     case 12: return v2_launch_kind<12, MODE>(a, kind, s);
     case 13: if constexpr (MODE != 2) return v2_launch_kind<13, MODE>(a, kind, s); else return hipErrorInvalidValue;
-    case 14: if constexpr (MODE != 2) return v2_launch_kind<14, MODE>(a, kind, s); else return hipErrorInvalidValue;
+    case 14:
+        if constexpr (MODE == 1) {
+            if (a.rows) return v2_launch_kind<214, MODE>(a, kind, s);
+        }
+        if constexpr (MODE != 2) return v2_launch_kind<14, MODE>(a, kind, s); else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
 }
