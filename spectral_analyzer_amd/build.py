@@ -100,6 +100,15 @@ VARIANTS = _unique([
     ("v3dnp", (["-DSPEC_V3D_PREFETCH_ALL=0"], ["spec_k_v3d.hip"])),
     # 32-point-per-thread plans: the window re-read from the L2-resident table every line (rounds 1-3) instead of a quarter Hann table in LDS
     ("v2wg", (["-DSPEC_V2_WIN_LDS=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip"])),
+    # round 5, A/B: the write-after-read barrier of an exchange in front of its stores (rounds 1-4) instead of right behind the
+    # previous exchange's loads; the radix-32 passes storing all 32 outputs behind the whole butterfly
+    ("v2late", (["-DSPEC_V2_EARLY_WAR=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
+    ("v2single", (["-DSPEC_V2_ST_SINGLE=1"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
+    ("v2prio", (["-DSPEC_V2_PRIO=3"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip"])),
+    ("v2prio1", (["-DSPEC_V2_PRIO=1"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip"])),
+    ("v2nofuse", (["-DSPEC_V2_FUSED_STORE=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
+    # development aid: per-wave shader-clock stamps at the phase boundaries of the Welch kernels (tools/v2_timeline.py)
+    ("v2stamp", (["-DSPEC_V2_STAMPS"], ["spec_k_v2w.hip"])),
     ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),
     ("v3he48", (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"])),
     ("v3he64", (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"])),
