@@ -101,14 +101,12 @@ VARIANTS = _unique([
     # 32-point-per-thread plans: the window re-read from the L2-resident table every line (rounds 1-3) instead of a quarter Hann table in LDS
     ("v2wg", (["-DSPEC_V2_WIN_LDS=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip"])),
     # round 5, A/B: the write-after-read barrier of an exchange in front of its stores (rounds 1-4) instead of right behind the
-    # previous exchange's loads; the radix-32 passes storing all 32 outputs behind the whole butterfly
-    ("v2late", (["-DSPEC_V2_EARLY_WAR=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
-    ("v2single", (["-DSPEC_V2_ST_SINGLE=1"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
-    ("v2prio", (["-DSPEC_V2_PRIO=3"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip"])),
-    ("v2prio1", (["-DSPEC_V2_PRIO=1"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip"])),
-    ("v2nofuse", (["-DSPEC_V2_FUSED_STORE=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
+    # previous exchange's loads
+    ("v2late", (["-DSPEC_V2_LATE_WAR=1"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
+    # round 5 experiment: 16384-point Welch segments through the plan 16 x (32 x 32) ("welch_rows" = 1; csrc/experiments/spec_v2_exp.h)
+    ("v2rows", (["-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
     # development aid: per-wave shader-clock stamps at the phase boundaries of the Welch kernels (tools/v2_timeline.py)
-    ("v2stamp", (["-DSPEC_V2_STAMPS"], ["spec_k_v2w.hip"])),
+    ("v2stamp", (["-DSPEC_V2_STAMPS", "-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
     ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),
     ("v3he48", (["-DV3H_EARLY_REGS=48"], ["spec_k_v3h.hip"])),
     ("v3he64", (["-DV3H_EARLY_REGS=64"], ["spec_k_v3h.hip"])),

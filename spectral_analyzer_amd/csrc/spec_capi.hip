@@ -79,7 +79,7 @@ struct spec_ctx {
     int64_t opt_small_single = 2;  // 8192-point fp32 lines through the same kernel (16 points per thread and half): 2 where measured faster, 1 always, 0 never
     int64_t opt_mid_single = 2;    // 16384-point fp32 lines through the same kernel: 2 where measured faster (run_lines), 1 always, 0 never
     int64_t opt_welch_two_pass = 0;
-    int64_t opt_welch_rows = 1;  // 16384-point Welch segments: the plan whose second exchange stays inside half a wave (spec_v2.h Plan2<214>); 0: 32 x 32 x 16
+    int64_t opt_welch_rows = 0;  // experiment library only (build.py --variant v2rows): 16384-point Welch segments through the plan 16 x (32 x 32)
     // the persistent large-N kernel: a launch whose abort word has not been looked at yet, and the verdict once a
     // bounded wait did time out on this context (shared / partitioned GPU): it is not tried again
     bool team_check_pending = false, team_disabled = false;
@@ -362,7 +362,13 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "rec_pread")) c->opt_rec_pread = value != 0;
     else if (!strcmp(key, "welch_two_pass")) c->opt_welch_two_pass = value != 0;
-    else if (!strcmp(key, "welch_rows")) c->opt_welch_rows = value != 0;
+    else if (!strcmp(key, "welch_rows")) {
+#ifdef SPEC_V2_ROWS
+        c->opt_welch_rows = value != 0;
+#else
+        if (value != 0) return fail(c, SPEC_EUNSUPPORTED, "welch_rows is an experiment: build the variant library (python -m spectral_analyzer_amd.build --variant v2rows)");
+#endif
+    }
     else if (!strcmp(key, "large_team")) {
         c->opt_large_team = value < 0 ? 0 : (value > 3 ? 3 : value);
         c->team_disabled = false;  // setting the knob gives the persistent launch another chance

@@ -203,57 +203,11 @@ template <typename V> __device__ __forceinline__ void pk_dft32(V (&u)[32]) {
     pk_dft32_comb_all(u, a0, a1, std::make_integer_sequence<int, 16>{});
 }
 
-// The same transform, decimation in frequency, outputs left in SPLIT order: u[k] = X[2k], u[16 + k] = X[2k + 1].
-// The two 16-point halves are independent once the sixteen radix-2 steps are done -- a caller that consumes the bins
-// where they stand (the Welch sums of spec_v2.h's row plan) is finished with the first half's 32 registers before the
-// second half starts; the natural-order form above keeps all 64 and both halves' temporaries to the end.
-template <int J, typename V> __device__ __forceinline__ void pk_dft32_dif_step(V (&u)[32]) {
-    const V s = u[J] + u[J + 16];
-    if constexpr (J == 8) {  // (a - b) W_32^8 = -i (a - b)
-        u[J + 16] = pk_mul_mi(u[J] - u[J + 16]);
-    } else {
-        u[J + 16] = pk_mul_w32<J>(u[J] - u[J + 16]);
-    }
-    u[J] = s;
-}
-template <typename V, int... J> __device__ __forceinline__ void pk_dft32_dif_steps(V (&u)[32], std::integer_sequence<int, J...>) {
-    (pk_dft32_dif_step<J>(u), ...);
-}
-template <typename V> __device__ __forceinline__ void pk_dft32_split(V (&u)[32]) {
-    pk_dft32_dif_steps(u, std::make_integer_sequence<int, 16>{});
-    V a[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = u[j];
-    pk_dft16(a);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) u[j] = a[j];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) a[j] = u[16 + j];
-    pk_dft16(a);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) u[16 + j] = a[j];
-}
-
-// natural order out by the decimation-in-frequency route (renaming only): the even bins are final after the first
-// 16-point half, so their stores can go out while the odd half is still being computed
-template <typename V> __device__ __forceinline__ void pk_dft32_dif(V (&u)[32]) {
-    pk_dft32_split(u);
-    V y[32];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { y[2 * k] = u[k]; y[2 * k + 1] = u[16 + k]; }
-#pragma unroll
-    for (int k = 0; k < 32; ++k) u[k] = y[k];
-}
-
-#ifndef SPEC_PK_DFT32_DIF
-#define SPEC_PK_DFT32_DIF 0
-#endif
 template <int RADIX, typename V> __device__ __forceinline__ void pk_dft(V (&u)[RADIX]) {
     if constexpr (RADIX == 2) pk_dft2(u[0], u[1]);
     else if constexpr (RADIX == 4) pk_dft4(u[0], u[1], u[2], u[3]);
     else if constexpr (RADIX == 8) pk_dft8(u);
     else if constexpr (RADIX == 16) pk_dft16(u);
-    else if constexpr (SPEC_PK_DFT32_DIF != 0) pk_dft32_dif(u);
     else pk_dft32(u);
 }
 

@@ -44,7 +44,7 @@ struct WelchArgs {
     void *final_out = nullptr;
     double norm = 0.0;
     int db = 0;
-    int rows = 0;               // launch_v2_welch, 16384 points: the plan with one workgroup-wide exchange ("welch_rows", spec_v2.h Plan2<214>)
+    int rows = 0;               // experiment library only ("welch_rows", -DSPEC_V2_ROWS): 16384 points through the plan 16 x (32 x 32)
 };
 
 int plan_lpw(int log2n);  // lines a workgroup transforms concurrently

@@ -58,25 +58,20 @@ template <> struct Plan2<113> {
     static constexpr int LINE = N + (N >> PADSH);
 };
 
-// Plan id 214 (round 5): 16384 points as 16 x (32 x 32) -- ONE workgroup-wide radix-16 step (decimation in frequency: the
-// twiddles W_N^(i r) follow the butterfly), then sixteen 1024-point rows, each owned by the 32 lanes of half a wave, whose
-// single exchange stays inside that half wave (no s_barrier; a wave's DS operations complete in order).  Two barriers
-// per line instead of four, the same arithmetic in another order.  A row's thread ends up with the bins
-// g + 16 l + 512 m (g = row, l = lane of the row): consecutive lanes are sixteen bins apart, so the plan serves the
-// kernels that do not store a line per transform -- the Welch sums (MODE 1) -- and nothing else.
-template <> struct Plan2<214> {
-    static constexpr int E = 32, N = 16384, T = N / E, NPASS = 3;
-    static constexpr int radix[4] = {16, 32, 32, 1};
-    static constexpr int WG = T, LPW = 1;
-    static constexpr bool WAVE_LOCAL = false;
-    static constexpr int PADSH = 5;
-    static constexpr int ROWS = 16, ROW = 1024 + 32;  // a row's region: 1024 elements + one pad per 32 (its own exchange)
-    static constexpr int LINE = ROWS * ROW;
-};
-template <int L> constexpr bool p2_rows() { return L == 214; }
-// multiple of T in the bin index of register m at the end of a transform: the row plan's last butterfly leaves its
-// outputs in split order (pk_dft32_split: even bins in the lower sixteen registers, odd bins in the upper)
-template <int L> constexpr int p2_bin_reg(int m) { return p2_rows<L>() ? (m < 16 ? 2 * m : 2 * (m - 16) + 1) : m; }
+// Experiments kept out of this file (csrc/experiments/spec_v2_exp.h; build.py --variant v2rows / v2stamp): the 16384-point Welch plan
+// 16 x (32 x 32) whose second exchange stays inside half a wave (Plan2<214>, measured slower: profiles/r05_rows.md), and the
+// per-wave phase stamps of tools/v2_timeline.py.  The product sees the three fall-backs below.
+#ifndef SPEC_V2_LATE_WAR
+#define SPEC_V2_LATE_WAR 0
+#endif
+#if defined(SPEC_V2_ROWS) || defined(SPEC_V2_STAMPS)
+#include "experiments/spec_v2_exp.h"
+#else
+template <int L> constexpr bool p2_rows() { return false; }
+template <int L> constexpr int p2_bin_reg(int m) { return m; }  // multiple of T in the bin index of register m after a transform
+#define V2_STAMP(sp, id) do { (void)(sp); } while (0)
+template <typename V> __device__ __forceinline__ void v2_fft_rows(V (&)[32], int, V *, const V *, V (&)[16], uint32_t *) {}
+#endif
 
 template <int L> constexpr int p2_P_of(int pass) {  // product of the radices before `pass`
     int p = 1;
@@ -222,84 +217,30 @@ __device__ __forceinline__ void v2_pass(V (&v)[Plan2<L>::E], int t, const V *tab
 
 // registers -> LDS after PASS.  Index of output r of butterfly i = t + s T:
 //   hi*(R P) + r P + k,  k = i mod P, hi = i / P      (Stockham autosort)
-// SPEC_V2_ST_SINGLE (A/B): exchange stores kept as single ds_write_b64 (volatile LDS pointer) instead of hipcc's ds_write2_b64 pairs
-#ifndef SPEC_V2_ST_SINGLE
-#define SPEC_V2_ST_SINGLE 0
-#endif
-template <typename V> struct lds_store_ptr {
-#if SPEC_V2_ST_SINGLE
-    typedef volatile __attribute__((address_space(3))) V *type;
-#else
-    typedef V *type;
-#endif
-};
-template <int L, int PASS, typename V> __device__ __forceinline__ void v2_store(const V (&v)[Plan2<L>::E], int t, V *lds_) {
+template <int L, int PASS, typename V> __device__ __forceinline__ void v2_store(const V (&v)[Plan2<L>::E], int t, V *lds) {
     using PL = Plan2<L>;
     constexpr int R = PL::radix[PASS], S = PL::E / R, P = p2_P<L, PASS>(), SH = PL::PADSH;
-    const typename lds_store_ptr<V>::type lds = (typename lds_store_ptr<V>::type)lds_;
     if constexpr (P >= 16) {  // wide stride: plain layout is conflict free
         static_assert(S == 1 || PL::T % P == 0, "butterfly s sits s*T*R elements further on");
-        const typename lds_store_ptr<V>::type base = lds + ((t & ~(P - 1)) * R + (t & (P - 1)));
+        V *base = lds + ((t & ~(P - 1)) * R + (t & (P - 1)));
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int r = 0; r < R; ++r) base[s * PL::T * R + r * P] = v[s + r * S];
     } else if constexpr (PASS == 0) {  // P == 1: a = i R + r, padded: pad(t R) + s*pad(T R) + r
         static_assert((PL::T * R) % (1 << SH) == 0 && R <= (1 << SH), "sub-line stride must be a multiple of the pad period");
-        const typename lds_store_ptr<V>::type base = lds + padn_rt<SH>(t * R);
+        V *base = lds + padn_rt<SH>(t * R);
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int r = 0; r < R; ++r) base[padn<SH>(s * PL::T * R) + r] = v[s + r * S];
     } else {  // 1 < P < 16, R = 16, S = 1: hi*(17 P) + k + pad(r P)
         static_assert(S == 1 && R == 16 && SH == 4, "middle passes are single radix-16 butterflies");
-        const typename lds_store_ptr<V>::type base = lds + ((t / P) * (17 * P) + (t & (P - 1)));
+        V *base = lds + ((t / P) * (17 * P) + (t & (P - 1)));
 #pragma unroll
         for (int r = 0; r < R; ++r) base[padn<4>(r * P)] = v[r];
     }
 }
-// Radix-32 pass and its exchange stores as ONE step (round 5; single butterfly per thread, S == 1): decimation in frequency --
-// sixteen radix-2 steps, then the even bins' 16-point half, whose outputs are stored at once, then the odd half.  The LDS
-// store path (the slowest part of an exchange: ~22 cycles per ds_write2_b64 with two waves per SIMD) works on the first
-// half's stores while the vector ALU computes the second half; with the natural-order butterfly (pk_dft32) every output is
-// final only at the very end and all 32 stores of all eight waves queue up behind the arithmetic.
-template <int L, int PASS, typename V>
-__device__ __forceinline__ void v2_pass_store32(V (&v)[Plan2<L>::E], int t, V *lds, const V *tab) {
-    using PL = Plan2<L>;
-    constexpr int R = PL::radix[PASS], P = p2_P<L, PASS>(), SH = PL::PADSH;
-    static_assert(R == 32 && PL::E == 32 && PASS + 1 < PL::NPASS, "one radix-32 butterfly per thread, not the last pass");
-    if constexpr (PASS > 0) {
-        const V *row = tab + p2_tab_off<L, PASS>() + (t & (P - 1));
-#pragma unroll
-        for (int r = 1; r < R; ++r) v[r] = pk_cmul(v[r], row[r * P]);
-    }
-    typename lds_store_ptr<V>::type base;
-    if constexpr (P >= 16) base = (typename lds_store_ptr<V>::type)(lds + ((t & ~(P - 1)) * R + (t & (P - 1))));  // output r at base[r P]
-    else {
-        static_assert(PASS == 0, "padded layout of the first pass");
-        base = (typename lds_store_ptr<V>::type)(lds + padn_rt<SH>(t * R));                                         // output r at base[r]
-    }
-    constexpr int RS = P >= 16 ? P : 1;
-    pk_dft32_dif_steps(v, std::make_integer_sequence<int, 16>{});
-    {
-        V a[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = v[j];
-        pk_dft16(a);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) base[(2 * k) * RS] = a[k];
-    }
-    __builtin_amdgcn_sched_barrier(0);  // the stores above are issued before the second half's arithmetic, not after it
-    {
-        V a[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = v[16 + j];
-        pk_dft16(a);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) base[(2 * k + 1) * RS] = a[k];
-    }
-}
-
 // LDS -> registers at stride T after the exchange written by PASS
 template <int L, int PASS, typename V> __device__ __forceinline__ void v2_load(V (&v)[Plan2<L>::E], int t, const V *lds) {
     using PL = Plan2<L>;
@@ -342,164 +283,37 @@ template <int L> __device__ __forceinline__ void v2_sync() {
     }
 }
 
-#ifndef SPEC_V2_EARLY_WAR
-#define SPEC_V2_EARLY_WAR 1
-#endif
-#ifndef SPEC_V2_PRIO
-#define SPEC_V2_PRIO 0
-#endif
-#ifndef SPEC_V2_FUSED_STORE
-#define SPEC_V2_FUSED_STORE 1
-#endif
-// Development aid (-DSPEC_V2_STAMPS, build.py --variant v2stamp; tools/v2_timeline.py): lane 0 of every wave notes the shader
-// clock at the phase boundaries of a line in LDS words of its own; never defined in a product build
-#ifdef SPEC_V2_STAMPS
-#define V2_STAMP(sp, id) do { __builtin_amdgcn_sched_barrier(0); if (sp) { const uint32_t c__ = (uint32_t)__builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) (sp)[id] = c__; } __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define V2_STAMP(sp, id) do { (void)(sp); } while (0)
-#endif
-
-// Plan2<214>: see the plan.  twl[r] = W_N^(r t) as for every plan; tab = W_1024^(m l).
-template <typename V>
-__device__ __forceinline__ void v2_fft_rows(V (&v)[32], int t, V *lds, const V *tab, V (&twl)[16], uint32_t *sp) {
-    using PL = Plan2<214>;
-    constexpr int ROW = PL::ROW;
-    // pass 0: butterfly s over the registers {s + 2 r} = x[i + 1024 r], i = t + 512 s; output r times W_N^(i r) =
-    // W_N^(t r) W_32^(s r)
-#ifndef SPEC_ABL_NOFFT
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        V u[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = v[s + 2 * r];
-        pk_dft16(u);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {
-            u[r] = pk_cmul(u[r], twl[r]);
-            if (s == 1) u[r] = r == 8 ? pk_mul_mi(u[r]) : pk_cmul_const(u[r], kW32[r][0], kW32[r][1]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[s + 2 * r] = u[r];
-    }
-#endif
-    V2_STAMP(sp, 2);
-#ifndef SPEC_ABL_NOLDS
-#if !defined(SPEC_ABL_NOBAR) && !SPEC_V2_EARLY_WAR
-    __syncthreads();  // every row of the previous line has been read
-#endif
-    V2_STAMP(sp, 3);
-    {   // element i of row r at r ROW + i: a wave writes 64 consecutive elements per instruction
-        V *base = lds + t;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) base[r * ROW + s * 512] = v[s + 2 * r];
-    }
-    V2_STAMP(sp, 4);
-#ifndef SPEC_ABL_NOBAR
-    __syncthreads();
-#endif
-    V2_STAMP(sp, 5);
-    const int l = t & 31;
-    V *row = lds + (t >> 5) * ROW;
-    // (volatile: kept as ds_read_b64.  The row's reads are 256 bytes apart and hipcc pairs them into ds_read2_b64, which
-    // takes twice the LDS cycles per byte -- MI355X_MICROARCH.md, LDS table -- and needs four consecutive registers)
-    // (address space 3 spelled out: a volatile access through a generic pointer would become a flat load)
-    typedef const volatile __attribute__((address_space(3))) V *lds_cvp;
-    const lds_cvp rowv = (lds_cvp)row;
-#pragma unroll
-    for (int m = 0; m < 32; ++m) v[m] = rowv[l + 32 * m];
-#endif
-    // the row's 1024-point transform, 32 x 32 on its 32 lanes: first pass without twiddles
-#ifndef SPEC_ABL_NOFFT
-    pk_dft32(v);
-#endif
-    V2_STAMP(sp, 6);
-#ifndef SPEC_ABL_NOLDS
-    // the row's own exchange (padded: lane l writes 33-element rows): the region is read and written by the lanes of
-    // this half wave only, and a wave's DS operations complete in issue order -- a scheduling fence is all it takes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        V *b = row + l * 33;
-#pragma unroll
-        for (int r = 0; r < 32; ++r) b[r] = v[r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    V2_STAMP(sp, 7);
-    // second pass: register m times W_1024^(m l), then the butterfly.  Values and twiddles are read SPEC_ROWS_CHUNK at a
-    // time: left alone the scheduler requests all 63 first and the twiddles alone hold 62 registers (16 spilled)
-#ifndef SPEC_ROWS_CHUNK
-#define SPEC_ROWS_CHUNK 16
-#endif
-    {
-        const lds_cvp tr = (lds_cvp)(tab + l);
-#pragma unroll
-        for (int c = 0; c < 32; c += SPEC_ROWS_CHUNK) {
-#pragma unroll
-            for (int m = c; m < c + SPEC_ROWS_CHUNK; ++m) {
-                v[m] = rowv[l + 33 * m];
-#ifndef SPEC_ABL_NOFFT
-                if (m > 0) v[m] = pk_cmul(v[m], tr[32 * m]);
-#endif
-            }
-            if (c + SPEC_ROWS_CHUNK < 32) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#if !defined(SPEC_ABL_NOBAR) && SPEC_V2_EARLY_WAR
-    __syncthreads();  // every row of this line has been read: the next line's first exchange may be written (see v2_fft)
-#endif
-    V2_STAMP(sp, 8);
-#endif
-#ifndef SPEC_ABL_NOFFT
-    pk_dft32_split(v);  // register p: bin 2 p (p < 16), 2 (p - 16) + 1 beyond -- p2_bin_reg
-#endif
-    V2_STAMP(sp, 9);
-}
-
 template <int L, int PASS = 0, typename V>
 __device__ __forceinline__ void v2_fft(V (&v)[Plan2<L>::E], int t, V *lds, const V *tab, V (&twl)[16], uint32_t *sp = nullptr) {
     using PL = Plan2<L>;
     if constexpr (p2_rows<L>()) {
-        v2_fft_rows(v, t, lds, tab, twl, sp);
+        v2_fft_rows(v, t, lds, tab, twl, sp);  // csrc/experiments/spec_v2_exp.h; never instantiated by the product
     } else {
         // SPEC_ABL_*: ablation builds of tools/ablate.sh (one stage removed, results wrong by construction,
         // DESIGN.md 4.7); never defined in a product build
-        constexpr bool FUSED = SPEC_V2_EARLY_WAR && SPEC_V2_FUSED_STORE && PL::E == 32 && PL::radix[PASS] == 32 && PASS + 1 < PL::NPASS;
-#if !defined(SPEC_ABL_NOFFT) && !defined(SPEC_ABL_NOLDS)
-        if constexpr (FUSED) v2_pass_store32<L, PASS>(v, t, lds, tab);
-        else
-#endif
-        {
 #ifndef SPEC_ABL_NOFFT
-            v2_pass<L, PASS>(v, t, tab, twl);
+        v2_pass<L, PASS>(v, t, tab, twl);
 #endif
-        }
         V2_STAMP(sp, 2 + 5 * PASS);
         if constexpr (PASS + 1 < PL::NPASS) {
 #ifndef SPEC_ABL_NOLDS
-#if !defined(SPEC_ABL_NOBAR) && !SPEC_V2_EARLY_WAR
-            v2_sync<L>();  // WAR: the previous exchange has been read by everyone
+#if !defined(SPEC_ABL_NOBAR) && SPEC_V2_LATE_WAR
+            v2_sync<L>();  // rounds 1-4: the write-after-read barrier in front of the stores (build.py --variant v2late)
 #endif
             V2_STAMP(sp, 3 + 5 * PASS);
-#ifndef SPEC_ABL_NOFFT
-            if constexpr (!FUSED)
-#endif
-                v2_store<L, PASS>(v, t, lds);
+            v2_store<L, PASS>(v, t, lds);
             V2_STAMP(sp, 4 + 5 * PASS);
 #ifndef SPEC_ABL_NOBAR
             v2_sync<L>();
 #endif
             V2_STAMP(sp, 5 + 5 * PASS);
             v2_load<L, PASS>(v, t, lds);
-#if !defined(SPEC_ABL_NOBAR) && SPEC_V2_EARLY_WAR
-            // WAR for the NEXT exchange's stores, taken as soon as this one has been read: the pass behind it (and, after a
-            // line's last exchange, everything up to the next line's first pass) then runs without a barrier between its
-            // arithmetic and its stores -- a wave stores while its SIMD's other wave computes (round 5: the per-wave time line
-            // showed all eight waves storing at once, 2 x 2 900 cycles of a 13 300-cycle segment with the vector ALU idle)
+#if !defined(SPEC_ABL_NOBAR) && !SPEC_V2_LATE_WAR
+            // The write-after-read barrier for the NEXT exchange's stores, taken as soon as this exchange has been read (round 5)
+            // instead of in front of those stores: the pass behind it -- and, after a line's last exchange, everything up to the
+            // next line's first pass -- runs without a barrier between its arithmetic and its stores, so a wave that is ahead
+            // stores while the others still compute.  Same number of barriers; cfg2 +3 %, cfg4 +2 %, 16384 / 32768 points +1 %
+            // (profiles/r05_ab_raw.txt).  The very first exchange of a kernel has nothing in front of it to wait for.
             if constexpr (!PL::WAVE_LOCAL) v2_sync<L>();  // (its release fence waits for the loads: lgkmcnt(0))
 #endif
             V2_STAMP(sp, 6 + 5 * PASS);
@@ -567,7 +381,7 @@ struct V2Args {
     void *final_out;        // MODE 1, one sub-line per unit: the finished PSDs (float[n_units][N]) instead of slabs
     double norm;            //         sum -> PSD factor (WelchArgs)
     int db;                 //         10 log10(psd + 1e-20)
-    int rows;               // MODE 1, 16384 points: Plan2<214> (16 rows of 1024 points, the second exchange inside half a wave)
+    int rows;               // experiment library only (-DSPEC_V2_ROWS): MODE 1, 16384 points through Plan2<214>
 };
 
 // MODE 0: spectrogram lines (MC:980-999 around SS:33-85); MODE 1: Welch partial sums; MODE 2: spectrogram
@@ -588,13 +402,6 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     v2f *tab = reinterpret_cast<v2f *>(smem + (size_t)PL::LPW * PL::LINE * 8);
     const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw);
 
-#if SPEC_V2_PRIO
-    // (A/B, round 5) whole-workgroup lines: the two waves of a SIMD (w and w + WG/128) at different priorities, so that one runs
-    // ahead and stores while the other still computes instead of both sharing the vector ALU and then both queueing at the LDS
-    if constexpr (!PL::WAVE_LOCAL && PL::WG >= 512) {
-        if (tid < PL::WG / 2) __builtin_amdgcn_s_setprio(SPEC_V2_PRIO);
-    }
-#endif
     // ---- one-time set-up: LDS twiddle tables of the middle passes, last-pass registers
     if constexpr (PL::NPASS > 2) fill_tables<L, 1>(tab, tw, tid);
     v2f twl[16];
@@ -887,9 +694,11 @@ template <int MODE> hipError_t v2_launch_n(const V2Args &a, int log2n, int kind,
     case 12: return v2_launch_kind<12, MODE>(a, kind, s);
     case 13: if constexpr (MODE != 2) return v2_launch_kind<13, MODE>(a, kind, s); else return hipErrorInvalidValue;
     case 14:
+#ifdef SPEC_V2_ROWS
         if constexpr (MODE == 1) {
             if (a.rows && (a.win_hann == 1 || a.win_hann == 2)) return v2_launch_kind<214, MODE>(a, kind, s);
         }
+#endif
         if constexpr (MODE != 2) return v2_launch_kind<14, MODE>(a, kind, s); else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
