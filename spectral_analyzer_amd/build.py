@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libspecgpu.so")
-SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_large.hip", "spec_k_team.hip", "spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2n.hip", "spec_k_v2h.hip", "spec_k_v3d.hip", "spec_k_v3h.hip", "spec_misc.hip", "spec_burst.hip"]
+SOURCES = ["spec_capi.hip", "spec_k_f32.hip", "spec_k_f64.hip", "spec_k_large.hip", "spec_k_team.hip", "spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2n.hip", "spec_k_v2h.hip", "spec_k_v2q.hip", "spec_k_v3d.hip", "spec_k_v3h.hip", "spec_misc.hip", "spec_burst.hip"]
 ARCH = "gfx950"
 # --offload-compress: the code objects are stored zstd-compressed in the library (about 360 kernel instantiations: 16 MB -> 2.5 MB);
 # the HIP runtime unpacks them when the library is loaded
@@ -105,6 +105,22 @@ VARIANTS = _unique([
     ("v2late", (["-DSPEC_V2_LATE_WAR=1"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip"])),
     # round 5 experiment: 16384-point Welch segments through the plan 16 x (32 x 32) ("welch_rows" = 1; csrc/experiments/spec_v2_exp.h)
     ("v2rows", (["-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
+    # ablations of the paired 65536-point kernel (results wrong by construction): every line re-reads the workgroup's first
+    # (the lines come from L1 / L2); no output stores; both
+    ("v2qnl", (["-DV2Q_ABL_NOLOAD"], ["spec_k_v2q.hip"])),
+    ("v2qns", (["-DV2Q_ABL_NOSTORE"], ["spec_k_v2q.hip"])),
+    ("v2qnn", (["-DV2Q_ABL_NOLOAD", "-DV2Q_ABL_NOSTORE"], ["spec_k_v2q.hip"])),
+    ("v2qnt", (["-DV2Q_ST_AUX=2"], ["spec_k_v2q.hip"])),
+    ("v2qst0", (["-DV2Q_ST_AUX=0"], ["spec_k_v2q.hip"])),
+    ("v2qst1", (["-DV2Q_ST_AUX=1"], ["spec_k_v2q.hip"])),
+    ("v2qst3", (["-DV2Q_ST_AUX=3"], ["spec_k_v2q.hip"])),
+    ("v2qst16", (["-DV2Q_ST_AUX=16"], ["spec_k_v2q.hip"])),
+    ("v2qst18", (["-DV2Q_ST_AUX=18"], ["spec_k_v2q.hip"])),
+    ("v2qld16", (["-DV2Q_LD_AUX=16"], ["spec_k_v2q.hip"])),
+    ("v2qm16", (["-DV2Q_ST_AUX=2", "-DV2Q_M0=1", "-DV2Q_M1=12", "-DV2Q_M2=16"], ["spec_k_v2q.hip"])),
+    ("v2qm12", (["-DV2Q_ST_AUX=2", "-DV2Q_M0=1", "-DV2Q_M1=8", "-DV2Q_M2=12"], ["spec_k_v2q.hip"])),
+    ("v2qm22", (["-DV2Q_ST_AUX=2", "-DV2Q_M0=2", "-DV2Q_M1=12", "-DV2Q_M2=22"], ["spec_k_v2q.hip"])),
+    ("v2qlnt", (["-DV2Q_LD_AUX=2"], ["spec_k_v2q.hip"])),
     # development aid: per-wave shader-clock stamps at the phase boundaries of the Welch kernels (tools/v2_timeline.py)
     ("v2stamp", (["-DSPEC_V2_STAMPS", "-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
     ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),

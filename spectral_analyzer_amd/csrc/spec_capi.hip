@@ -76,6 +76,8 @@ struct spec_ctx {
     int64_t opt_force_generic = 0, opt_lines_per_wg = 0, opt_large_chunk_mb = 1024, opt_stage_chunk_mb = 64;
     int64_t opt_large_team = 1, opt_large_ring = 0, opt_large_wg = 512, opt_large_block = 0, opt_rec_pread = 0;
     int64_t opt_large_single = 1;  // 32768-point fp32 lines in one workgroup (spec_k_v2h.hip); 0: the four-step path
+    int64_t opt_pair_interleave = 1;  // the paired kernel's line order: the pairs of an XCD walk one block of lines together (spec_k_v2q.hip)
+    int64_t opt_large_pair = 1;    // 65536-point fp32 lines by pairs of single-workgroup kernels (spec_k_v2q.hip); 0: the four-step team kernel
     int64_t opt_small_single = 2;  // 8192-point fp32 lines through the same kernel (16 points per thread and half): 2 where measured faster, 1 always, 0 never
     int64_t opt_mid_single = 2;    // 16384-point fp32 lines through the same kernel: 2 where measured faster (run_lines), 1 always, 0 never
     int64_t opt_welch_two_pass = 0;
@@ -379,6 +381,8 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(key, "large_team_fake_abort")) c->opt_team_fake_abort = value != 0;
     else if (!strcmp(key, "large_single")) c->opt_large_single = value != 0;
+    else if (!strcmp(key, "large_pair")) c->opt_large_pair = value != 0;
+    else if (!strcmp(key, "pair_interleave")) c->opt_pair_interleave = value != 0;
     else if (!strcmp(key, "mid_single")) c->opt_mid_single = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "small_single")) c->opt_small_single = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "multi_verify")) c->opt_multi_verify = value != 0;
@@ -396,7 +400,7 @@ spec_status spec_get_option(spec_ctx *c, const char *key, int64_t *value) {
     struct { const char *k; int64_t v; } tab[] = {
         {"force_generic", c->opt_force_generic}, {"lines_per_wg", c->opt_lines_per_wg}, {"large_chunk_mb", c->opt_large_chunk_mb},
         {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass}, {"welch_rows", c->opt_welch_rows},
-        {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"mid_single", c->opt_mid_single}, {"small_single", c->opt_small_single},
+        {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"large_pair", c->opt_large_pair}, {"pair_interleave", c->opt_pair_interleave}, {"mid_single", c->opt_mid_single}, {"small_single", c->opt_small_single},
         {"large_block", c->opt_large_block}, {"render_fused", c->opt_render_fused}, {"readahead_lines", c->opt_readahead_lines},
         {"large_team_fake_abort", c->opt_team_fake_abort}, {"large_team_disabled", c->team_disabled ? 1 : 0},
         {"multi_verify", c->opt_multi_verify}, {"multi_verify_corrupt", c->opt_multi_verify_corrupt}, {"multi_peer_access", c->multi_peer_access}, {"multi_verified", c->multi_verified},
@@ -620,6 +624,32 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
             hipError_t e = launch_v2h_spectro(a, log2n, tw_half, tw_full64, (uint32_t)run, c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "32768-point launch: %s", hipGetErrorString(e));
+            done += a.n_lines;
+        }
+        return SPEC_OK;
+    }
+    if (large && !f64 && c->opt_large_pair && c->opt_large_team == 1 && !d_sel && v2q_applicable(log2n, a.kind, a.out_fmt, n_lines, hop)) {
+        // 65536-point fp32 lines: a PAIR of workgroups per line, each a single-workgroup kernel on a radix-4 step's even or odd
+        // outputs (spec_k_v2q.hip); no hand-off, no waiting.  The default dispatch only, as above.
+        const void *tw_q = nullptr, *tw_full64 = nullptr;
+        if ((st = get_twiddles(c, log2n, false, &a.tw)) != SPEC_OK) return st;
+        if ((st = get_twiddles(c, log2n - 2, false, &tw_q)) != SPEC_OK) return st;
+        if (a.win && (st = get_twiddles(c, log2n, true, &tw_full64)) != SPEC_OK) return st;
+        uint64_t done = 0;
+        while (done < n_lines) {
+            const uint64_t rem = n_lines - done;
+            // one workgroup per CU: n_cu / 2 pairs at a time; long runs (the set-up is worth about a line), two rounds when short
+            const uint64_t pairs_wanted = (uint64_t)c->n_cu;
+            uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg : (rem + pairs_wanted - 1) / pairs_wanted;
+            if (run < 1) run = 1;
+            if (run > 32) run = 32;
+            const uint64_t ilv = c->opt_pair_interleave ? 16 : 1;  // a pair's lines are `ilv` apart
+            while (run > 1 && run * ilv * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;  // 32-bit offsets in a span
+            a.n_lines = rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_v2q_spectro(a, tw_q, tw_full64, (uint32_t)run, (int)c->opt_pair_interleave, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "65536-point launch: %s", hipGetErrorString(e));
             done += a.n_lines;
         }
         return SPEC_OK;

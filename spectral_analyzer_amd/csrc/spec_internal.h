@@ -91,6 +91,11 @@ hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t 
 // W_(N/2) table, w.win = non-null for the Hann window; `run` consecutive lines per workgroup
 bool v2h_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v2h_spectro(const WfArgs &w, int log2n, const void *tw_half, const void *tw_full64, uint32_t run, hipStream_t s);  // tw_full64: v2d W_N table, needed with a window
+// 65536-point fp32 lines by PAIRS of workgroups (spec_k_v2q.hip): w.tw = v2f W_65536 table, tw_q = v2f W_16384 table,
+// tw_full64 = v2d W_65536 table (needed with a window); `run` consecutive lines per pair
+bool v2q_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop);
+// interleave: the sixteen pairs of an XCD take every sixteenth line of a shared block of 16 * run lines (L2 then serves the overlap)
+hipError_t launch_v2q_spectro(const WfArgs &w, const void *tw_q, const void *tw_full64, uint32_t run, int interleave, hipStream_t s);
 // 16384-point fp64 lines in one workgroup (spec_k_v3h.hip): w.tw = v2d W_16384 table, tw_half = v2d W_8192 table
 bool v3h_applicable(int log2n, int kind, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v3h_spectro(const WfArgs &w, const void *tw_half, uint32_t run, hipStream_t s);
