@@ -62,6 +62,74 @@ FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
 SEED = 0x5EC7A11A
 
 
+class ClockSampler:
+    """Shader / memory clock, power and temperature of one GPU, read from sysfs (hwmon of the device's PCI function) by a host
+    thread -- no child process, no HIP call, nothing on the stream that is being timed.  VERDICT r04 item 4: every number of the
+    bench line carries the clock and power state it was measured at (the 4096-point kernels run at 5+ TB/s and the boxes of the
+    pool read 0.63 ... 0.66 for cfg2: a power or thermal cap is part of the roofline story)."""
+
+    FIELDS = (("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6), ("power_w", "power1_average", 1e-6),
+              ("power_w", "power1_input", 1e-6), ("temp_c", "temp2_input", 1e-3), ("temp_c", "temp1_input", 1e-3))
+
+    def __init__(self, device_index: int):
+        self.dir, self.err, self.samples, self._stop, self._thr = None, None, [], False, None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            addr = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+            base = os.path.join("/sys/bus/pci/devices", addr, "hwmon")
+            hw = sorted(os.listdir(base))
+            self.dir = os.path.join(base, hw[0])
+            self.files = {}
+            for key, name, scale in self.FIELDS:
+                f = os.path.join(self.dir, name)
+                if key not in self.files and os.path.exists(f):
+                    self.files[key] = (f, scale)
+            if not self.files:
+                raise OSError("no clock / power files under " + self.dir)
+            self.pci = addr
+        except Exception as e:  # noqa: BLE001 -- a box without readable sysfs still benches; the line says why
+            self.err = "%s: %s" % (type(e).__name__, e)
+
+    def read(self):
+        out = {}
+        for key, (f, scale) in self.files.items():
+            try:
+                out[key] = float(open(f).read().strip()) * scale
+            except (OSError, ValueError):
+                pass
+        return out
+
+    def start(self, period_s: float = 0.001):
+        if self.err:
+            return
+        import threading
+        self.idle = self.read()
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self.read())
+                time.sleep(period_s)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop = True
+            self._thr.join()
+        if self.err:
+            return {"source": "sysfs hwmon", "error": self.err}
+        out = {"source": "sysfs hwmon of " + self.pci, "samples": len(self.samples), "idle_before": self.idle}
+        try:
+            out["power_cap_w"] = float(open(os.path.join(self.dir, "power1_cap")).read()) * 1e-6
+        except (OSError, ValueError):
+            pass
+        for key in self.files:
+            v = sorted(x[key] for x in self.samples if key in x)
+            if v:
+                out[key] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+        return out
+
+
 def usable_cores() -> int:
     """CPU threads this process may actually run on: affinity mask, capped by a cgroup quota."""
     n = len(os.sched_getaffinity(0))
@@ -208,10 +276,13 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    clocks = ClockSampler(local_rank) if rank == 0 else None
     for _ in range(args.warmup):
         step()
     fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if clocks is not None:
+        clocks.start()   # a host thread reading sysfs while the timed steps run
     t0 = time.perf_counter()
     for a, b in ev:
         a.record(stream)
@@ -219,6 +290,7 @@ def main() -> None:
         b.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    clock_state = clocks.stop() if clocks is not None else None
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if dist is not None:
@@ -320,7 +392,7 @@ def main() -> None:
             hbm = n_psd * b_psd / (kern_ms * 1e-3) / 1e9
             roof = {"bound": "valu", "achieved": tfl, "peak": FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                     "frac": tfl / FP32_VECTOR_TFLOPS, "traffic": traffic, "traffic_measured_at": traffic_stamp,
-                    "kernel_ms": kern_ms,
+                    "kernel_ms": kern_ms, "clocks": clock_state,
                     "flops_per_segment": 5.0 * nfft * np.log2(nfft), "segments_per_launch": n_lines,
                     "hbm_achieved_GBps": hbm, "hbm_frac": hbm / HBM_PEAK_GBPS, "bytes_per_psd": b_psd,
                     "psd_per_s": n_psd * world * args.steps / elapsed}
@@ -334,7 +406,7 @@ def main() -> None:
             achieved = n_lines * b_line / (kern_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_measured_at": traffic_stamp,
-                    "kernel_ms": kern_ms, "bytes_per_line": b_line, "lines_per_launch": n_lines,
+                    "kernel_ms": kern_ms, "clocks": clock_state, "bytes_per_line": b_line, "lines_per_launch": n_lines,
                     # extras: reads only (the north star is phrased on reads) and the box's own copy rate
                     "read_frac": n_lines * hop * bps / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "copy_GBps": copy_gbps,

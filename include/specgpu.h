@@ -21,6 +21,22 @@
  *     with SPEC_EDEVICE.
  *   - device-pointer calls are asynchronous on the context's stream; host-pointer
  *     calls return after the results are in the caller's memory.
+ *
+ * Numerical contract (FROZEN in round 5; asserted by tests/test_gpu_parity.py and, for the drop-in, by
+ * integration/java-test/SpectralServiceParityTest.java -- these are the figures a host author may rely on).
+ * With M = max_k |X[k]| of a line and the reference = SpectralService.computeMagnitudes (fp64, commons-math3 3.6.1):
+ *   fp32 pipeline (SPEC_OUT_*_F32 from cu8 / ci8 / ci16 / cf32 input):
+ *     every bin:               | |X| - |X|_ref |  <=  4e-6 M log2(nfft)
+ *     bins with |X| >= 1e-4 M: | dB - dB_ref |    <=  8.686 * 1.2e-7 * M / |X| + 2e-5      (a noise floor of at most 1.2e-7 M:
+ *                                                     1.1e-3 dB on a bin of 1e-3 M, 1.0e-2 dB on a bin of 1e-4 M)
+ *   fp64 pipeline (SPEC_OUT_*_F64, cf64 input, spec_compute_magnitudes -- the drop-in's double[]):
+ *     bins with |X| >= 1e-9 M: | |X| - |X|_ref |  <=  max(8e-15 log2(nfft) + 5e-14, 4e-17 nfft) M
+ *     bins with |X| >= 1e-5 M: | dB - dB_ref |    <=  max(1e-9, 3e-12 nfft) dB
+ *     (the nfft-proportional terms are the REFERENCE transform's own rounding error -- its twiddles are running products;
+ *     against the exact DFT the fp64 pipeline is within 1e-15 M and 1e-10 dB at every size, which the suite also asserts)
+ *   Welch PSD: 5e-6 of the PSD's peak (fp32 pipeline), 1e-9 (fp64 entry) against the build's stated estimator (JDSP's is unknown).
+ * The suite additionally holds the kernels to REGRESSION bounds at about three times what they measure today
+ * (linear 5e-7 M log2 nfft; 2e-3 dB down to 1e-3 M, 4e-3 dB down to 1e-4 M on its fixed inputs): tighter than the contract, not part of it.
  */
 #ifndef SPECGPU_H
 #define SPECGPU_H
@@ -153,6 +169,17 @@ void *spec_stream(const spec_ctx *ctx);
  *   "small_single" = 2 | 1 | 0   8192-point fp32 lines through it (16 points per thread and half, three workgroups per CU):
  *                     2 (default) = cf32 where the family's kernel has no register-reuse variant (big-endian files, hops other
  *                     than N/4, N/2, N; 8 ... 11 points of the roofline faster; level everywhere else), 1 = always, 0 = never
+ *   "large_pair" = 1 | 0   65536-point fp32 lines (the default dispatch, "large_team" = 1): 1 (default) = a PAIR of workgroups
+ *                     per line, each a single-workgroup kernel on two of the four outputs of a radix-4 step taken in registers
+ *                     (two 16384-point transforms each; nothing is handed over, nothing waits): 1.04x ... 5.3x the four-step
+ *                     team kernel in all 30 measured format / hop / window cases (cf32 0.25 -> 0.31 of 8 TB/s, ci16 0.09 -> 0.34);
+ *                     0 = the four-step paths of "large_team"
+ *   "pair_interleave" = 1 | 0   line order of that kernel: 1 (default) = the sixteen pairs of an XCD walk one block of lines
+ *                     together (pair s takes lines s, s + 16, ...: what a line shares with its neighbour is in that XCD's L2),
+ *                     0 = consecutive lines per pair
+ *   "debug_twiddle_bits" = k (tests)  twiddle tables built from now on lose their k low mantissa bits -- a deliberately
+ *                     degraded transform for the suite's mutation test; accepted only before a context's first transform
+ *   "welch_rows" = 1 (experiment library lib/libspecgpu_v2rows.so only; the product returns SPEC_EUNSUPPORTED)
  *   "multi_verify" = 0 | 1   spec_waterfall_multi / spec_welch_psd_multi with a device-resident result: 1 = every piece a
  *                     peer context sends is checksummed on its own device before it leaves and again where it landed on
  *                     the consumer's device; a difference is SPEC_EDEVICE and the message names piece, devices and the path

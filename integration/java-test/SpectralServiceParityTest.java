@@ -47,8 +47,9 @@ import org.junit.jupiter.api.TestFactory;
  *       (the reference applies no window).</li>
  *   <li><b>with the drop-in classes of {@code integration/java/} installed</b> and
  *       {@code -Dspecgpu.dropin=true -Djava.library.path=...}: the same lines through JNI and the GPU, held to the
- *       fp64 statement of {@code tests/test_gpu_parity.py} (every bin {@code >= 1e-9 M}:
- *       {@code ||X|_gpu - |X|_ref| <= max(8e-15 log2 N + 5e-14, 4e-17 N) M}); cf64 fixtures are then compared with
+ *       fp64 contract of {@code include/specgpu.h} (every bin {@code >= 1e-9 M}:
+ *       {@code ||X|_gpu - |X|_ref| <= max(8e-15 log2 N + 5e-14, 4e-17 N) M}; every bin {@code >= 1e-5 M}:
+ *       {@code |dB_gpu - dB_ref| <= max(1e-9, 3e-12 N)}); cf64 fixtures are then compared with
  *       their decoded lines ({@code ExtractDownConvertService.java:79-81}).</li>
  * </ul>
  */
@@ -92,7 +93,7 @@ class SpectralServiceParityTest {
         assertEquals((long) lines * nfft * 8, exp.capacity());
 
         SpectralService service = new SpectralService();
-        double worstUlps = 0, worstLin = 0;
+        double worstUlps = 0, worstLin = 0, worstDb = 0;
         for (int l = 0; l < lines; l++) {
             double[] got = service.computeMagnitudes(buffer, l * hop * bps, nfft, datatype);
             assertEquals(nfft, got.length);
@@ -115,13 +116,20 @@ class SpectralServiceParityTest {
                     if (mw < 1e-9 * peak) {
                         continue;   // below that the + 1e-10 of SpectralService.java:81 takes over
                     }
+                    // the fp64 contract of include/specgpu.h ("Numerical contract"), both statements
                     final double tol = Math.max(8e-15 * (Math.log(nfft) / Math.log(2)) + 5e-14, 4e-17 * nfft);
                     final double lin = Math.abs(mg - mw) / peak;
                     worstLin = Math.max(worstLin, lin);
                     assertTrue(lin <= tol, name + " line " + l + " bin " + i + ": " + lin + " M > " + tol + " M");
+                    if (mw >= 1e-5 * peak) {
+                        final double dbTol = Math.max(1e-9, 3e-12 * nfft);
+                        final double db = Math.abs(got[i] - want);
+                        worstDb = Math.max(worstDb, db);
+                        assertTrue(db <= dbTol, name + " line " + l + " bin " + i + ": " + db + " dB > " + dbTol + " dB");
+                    }
                 }
             }
         }
-        System.out.println(name + (DROP_IN ? ": max linear error " + worstLin + " M" : ": max " + worstUlps + " ulp"));
+        System.out.println(name + (DROP_IN ? ": max linear error " + worstLin + " M, max dB error " + worstDb : ": max " + worstUlps + " ulp"));
     }
 }

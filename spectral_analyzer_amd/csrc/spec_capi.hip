@@ -80,6 +80,7 @@ struct spec_ctx {
     int64_t opt_large_pair = 1;    // 65536-point fp32 lines by pairs of single-workgroup kernels (spec_k_v2q.hip); 0: the four-step team kernel
     int64_t opt_small_single = 2;  // 8192-point fp32 lines through the same kernel (16 points per thread and half): 2 where measured faster, 1 always, 0 never
     int64_t opt_mid_single = 2;    // 16384-point fp32 lines through the same kernel: 2 where measured faster (run_lines), 1 always, 0 never
+    int64_t opt_debug_twiddle_bits = 0;  // test hook: twiddle tables built from now on lose this many mantissa bits (tests/test_gpu_parity.py mutation test)
     int64_t opt_welch_two_pass = 0;
     int64_t opt_welch_rows = 0;  // experiment library only (build.py --variant v2rows): 16384-point Welch segments through the plan 16 x (32 x 32)
     // the persistent large-N kernel: a launch whose abort word has not been looked at yet, and the verdict once a
@@ -364,6 +365,11 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "stage_chunk_mb")) c->opt_stage_chunk_mb = value < 1 ? 1 : value;
     else if (!strcmp(key, "rec_pread")) c->opt_rec_pread = value != 0;
     else if (!strcmp(key, "welch_two_pass")) c->opt_welch_two_pass = value != 0;
+    else if (!strcmp(key, "debug_twiddle_bits")) {
+        // a deliberately degraded transform for the suite's mutation test: only on a context that has built no table yet
+        if (!c->twiddles.empty()) return fail(c, SPEC_EINVAL, "debug_twiddle_bits must be set before the first transform of a context");
+        c->opt_debug_twiddle_bits = value < 0 ? 0 : (value > 20 ? 20 : value);
+    }
     else if (!strcmp(key, "welch_rows")) {
 #ifdef SPEC_V2_ROWS
         c->opt_welch_rows = value != 0;
@@ -399,7 +405,7 @@ spec_status spec_get_option(spec_ctx *c, const char *key, int64_t *value) {
     if (!key || !value) return fail(c, SPEC_EINVAL, "spec_get_option: null argument");
     struct { const char *k; int64_t v; } tab[] = {
         {"force_generic", c->opt_force_generic}, {"lines_per_wg", c->opt_lines_per_wg}, {"large_chunk_mb", c->opt_large_chunk_mb},
-        {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass}, {"welch_rows", c->opt_welch_rows},
+        {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass}, {"debug_twiddle_bits", c->opt_debug_twiddle_bits}, {"welch_rows", c->opt_welch_rows},
         {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"large_pair", c->opt_large_pair}, {"pair_interleave", c->opt_pair_interleave}, {"mid_single", c->opt_mid_single}, {"small_single", c->opt_small_single},
         {"large_block", c->opt_large_block}, {"render_fused", c->opt_render_fused}, {"readahead_lines", c->opt_readahead_lines},
         {"large_team_fake_abort", c->opt_team_fake_abort}, {"large_team_disabled", c->team_disabled ? 1 : 0},
@@ -429,6 +435,16 @@ static spec_status get_twiddles(spec_ctx *c, int log2n, bool f64, const void **o
         const long double cr = cosl(a), ci = sinl(a);
         if (f64) { double *p = reinterpret_cast<double *>(host.data()) + 2 * m; p[0] = (double)cr; p[1] = (double)ci; }
         else { float *p = reinterpret_cast<float *>(host.data()) + 2 * m; p[0] = (float)cr; p[1] = (float)ci; }
+    }
+    if (c->opt_debug_twiddle_bits > 0) {  // "debug_twiddle_bits": drop the low mantissa bits of every entry (truncation)
+        const int k = (int)c->opt_debug_twiddle_bits;
+        if (f64) {
+            uint64_t *q = reinterpret_cast<uint64_t *>(host.data());
+            for (size_t i = 0; i < 2 * n; ++i) q[i] &= ~((1ull << (k + 29)) - 1);  // (a double carries 29 bits more than a float)
+        } else {
+            uint32_t *q = reinterpret_cast<uint32_t *>(host.data());
+            for (size_t i = 0; i < 2 * n; ++i) q[i] &= ~((1u << k) - 1);
+        }
     }
     void *dev = nullptr;
     HIP_TRY(c, hipMalloc(&dev, n * esz));

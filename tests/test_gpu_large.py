@@ -57,10 +57,12 @@ def test_product_library_refuses_the_experiment_geometries(svc, oracle):
     iq = torch.from_numpy(oracle.synth_iq("cf32_le", 1, 0, 65 * 16384 + 65536)).cuda()
     try:
         svc.set_option("large_wg", 256)
-        with pytest.raises(NotImplementedError, match="experiment geometry"):   # (65536 points: 32768-point fp32 lines no
-            svc.compute_waterfall(iq, 0, 65536, "cf32_le", 65, hop=16384)       #  longer take the team kernel by default)
+        svc.set_option("large_pair", 0)     # (fp32 lines of 32768 / 65536 points no longer take the team kernel by default)
+        with pytest.raises(NotImplementedError, match="experiment geometry"):
+            svc.compute_waterfall(iq, 0, 65536, "cf32_le", 65, hop=16384)
     finally:
         svc.set_option("large_wg", 512)
+        svc.set_option("large_pair", 1)
 
 
 CASES = [  # datatype, nfft, hop, n_lines, window, fp64 output
@@ -142,6 +144,7 @@ def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nf
     import torch
     iq = torch.from_numpy(oracle.synth_iq(datatype, 31, 3, (n_lines - 1) * hop + nfft)).cuda()
     svc.set_option("large_single", 0)      # (32768-point fp32 lines: the four-step paths are what this test is about)
+    svc.set_option("large_pair", 0)        # (65536-point fp32 lines likewise)
     try:
         out = {}
         for mode in (0, 3, 2, 1):
@@ -154,6 +157,7 @@ def test_guarded_fallback_is_one_self_contained_launch(svc, oracle, datatype, nf
     finally:
         svc.set_option("large_team", 1)
         svc.set_option("large_single", 1)
+        svc.set_option("large_pair", 1)
 
 
 def test_a_context_stops_trying_the_team_kernel_after_one_abort(oracle):

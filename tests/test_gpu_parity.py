@@ -1,5 +1,8 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the
-same seeded inputs.  Tolerances are the ones stated in SURVEY.md 8(c):
+same seeded inputs.  The tolerances below are the numerical contract of include/specgpu.h, FROZEN in round 5 (this docstring
+keeps the history of how they got there; no figure has changed since).  Beside them the deterministic suite asserts
+REGRESSION bounds at about three times the maxima it measures today (REG_*: a kernel that loses a decimal digit fails them
+long before it reaches the contract), and test_degraded_twiddles_turn_the_suite_red proves that they bite.
 
 fp32 pipeline (reference is fp64):  with M = max_k |X[k]| of the line,
     * every bin:                 | |X|_gpu - |X|_ref |  <=  4e-6 * M * log2(N)
@@ -41,16 +44,27 @@ pytestmark = pytest.mark.gpu
 DTYPES = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "cf64_be"]
 
 
-FP32_FLOOR = 1.2e-7   # noise floor of the fp32 pipeline relative to the line's peak magnitude (worst seen: 6.5e-8)
+# ---- the contract (include/specgpu.h) ----
+FP32_LIN = 4e-6       # | |X| - |X|_ref | <= FP32_LIN M log2 N on every bin
+FP32_FLOOR = 1.2e-7   # noise floor of the fp32 pipeline relative to the line's peak magnitude (worst seen in 25 000 random requests: 6.5e-8)
+# ---- regression guards of the deterministic suite (about 3x the maxima observed on its fixed inputs, round 4: linear 1.7e-7,
+# 4.4e-4 dB down to 1e-3 M, 1.6e-3 dB down to 1e-4 M; the two dB tiers are the statements of rounds 1-3).  The extended random
+# runs (SPEC_FUZZ_EXTRA_SEEDS) check the contract only: over tens of thousands of lines the weak-bin maximum creeps past any flat tier.
+REG_LIN = 5e-7
+REG_DB_1E3 = 2e-3
+REG_DB_1E4 = 4e-3
+REGRESSION_DEFAULT = not int(__import__("os").environ.get("SPEC_FUZZ_EXTRA_SEEDS", "0"))
 
 
-def check_fp32(db_gpu, db_ref, nfft):
-    """db arrays [lines, nfft]; applies both fp32 statements (linear on every bin, noise-floor dB bound down to 1e-4 M)."""
+def check_fp32(db_gpu, db_ref, nfft, regression=None):
+    """db arrays [lines, nfft]; applies both fp32 statements of the contract (linear on every bin, noise-floor dB bound down
+    to 1e-4 M) and, unless regression=False (extended random runs), the suite's regression guards."""
+    regression = REGRESSION_DEFAULT if regression is None else regression
     mag_g = 10.0 ** (db_gpu.astype(np.float64) / 20.0)
     mag_r = 10.0 ** (db_ref / 20.0)
     M = mag_r.max(axis=1, keepdims=True)
     lin_err = np.abs(mag_g - mag_r) / (M * np.log2(nfft))
-    assert lin_err.max() <= 4e-6, "linear error %.3g > 4e-6 M log2 N" % lin_err.max()
+    assert lin_err.max() <= FP32_LIN, "linear error %.3g > %.3g M log2 N" % (lin_err.max(), FP32_LIN)
     db_abs = np.abs(db_gpu.astype(np.float64) - db_ref)
     sel = mag_r >= 1e-4 * M
     bound = 8.686 * FP32_FLOOR * (M / np.maximum(mag_r, 1e-300)) + 2e-5
@@ -59,7 +73,13 @@ def check_fp32(db_gpu, db_ref, nfft):
         i = np.unravel_index(np.argmax(over), over.shape)
         raise AssertionError("dB error %.3g on a bin of %.3g M: beyond the noise-floor bound %.3g (floor %.2g M)"
                              % (db_abs[i], mag_r[i] / M[i[0], 0], bound[i], FP32_FLOOR))
-    return lin_err.max(), db_abs[mag_r >= 1e-3 * M].max(), db_abs[sel].max()
+    d3 = db_abs[mag_r >= 1e-3 * M].max()
+    d4 = db_abs[sel].max()
+    if regression:
+        assert lin_err.max() <= REG_LIN, "REGRESSION guard: linear error %.3g > %.3g M log2 N (contract %.3g)" % (lin_err.max(), REG_LIN, FP32_LIN)
+        assert d3 <= REG_DB_1E3, "REGRESSION guard: %.3g dB on a bin >= 1e-3 M (guard %.3g)" % (d3, REG_DB_1E3)
+        assert d4 <= REG_DB_1E4, "REGRESSION guard: %.3g dB on a bin >= 1e-4 M (guard %.3g)" % (d4, REG_DB_1E4)
+    return lin_err.max(), d3, d4
 
 
 def fp64_tol(nfft):
@@ -179,30 +199,94 @@ def test_fp64_family_all_variants(svc, oracle, nfft, datatype, hop_div, window):
 
 
 # ---- the fp64 pipeline against the EXACT transform (no oracle, no reference in between) ---------------------------------
-@pytest.mark.parametrize("nfft", [1024, 4096, 8192, 16384, 65536])
+def _exact_magnitudes(xc, cols, nfft):
+    """|X| of the columns `cols` (fftshifted, SS:78) of one line by a DFT evaluated in long double."""
+    k = ((cols - nfft // 2) % nfft).astype(np.longdouble)[:, None]       # column c holds bin (c - N/2) mod N
+    n = np.arange(nfft, dtype=np.longdouble)[None, :]
+    two_pi = 2 * np.longdouble("3.14159265358979323846264338327950288")
+    out = np.empty(len(cols), dtype=np.float64)
+    for a in range(0, len(cols), 32):                                    # (in pieces: 192 x 65536 complex long doubles at once is 400 MB)
+        X = (np.exp(-1j * (two_pi * ((k[a:a + 32] * n) % nfft) / nfft)) * xc[None, :]).sum(axis=1)
+        out[a:a + 32] = np.abs(X).astype(np.float64)
+    return out
+
+
+def _probe_columns(mag, nfft, weakest):
+    """192 columns of one line: the strongest, the weakest above `weakest` M, and a stride through the rest."""
+    M = mag.max()
+    order = np.argsort(mag)
+    weak = order[np.searchsorted(mag[order], weakest * M):][:32]
+    return np.unique(np.concatenate([order[-32:], weak, np.arange(0, nfft, nfft // 128)]))
+
+
+@pytest.mark.parametrize("nfft", [1024, 4096, 8192, 16384, 32768, 65536])
 @pytest.mark.parametrize("datatype", ["cf64_le", "cf32_le"])
 def test_fp64_lines_against_a_long_double_dft(svc, oracle, nfft, datatype):
     """Every fp64 kernel of the dispatch (family, 8192-point plan with LDS twiddles, single-workgroup 16384-point kernel, team /
-    two-launch four-step at 65536) against a DFT evaluated in long double for 192 bins of one line (the strongest, the weakest
-    above 1e-5 M, and a stride through the rest): | |X|_gpu - |X|_exact | <= 1e-15 M on every one of them, |dB| <= 1e-10 on those
-    >= 1e-5 M.  The parity tolerances above are wider only because the REFERENCE's transform is (its twiddle recurrence)."""
+    two-launch four-step at 32768 and 65536) against a DFT evaluated in long double for 192 bins of one line (the strongest, the
+    weakest above 1e-5 M, and a stride through the rest): | |X|_gpu - |X|_exact | <= 1e-15 M on every one of them, |dB| <= 1e-10 on
+    those >= 1e-5 M.  The parity tolerances above are wider only because the REFERENCE's transform is (its twiddle recurrence)."""
     iq = oracle.synth_iq(datatype, seed=nfft // 512 + 3, first_sample=0, n_samples=nfft)
     x = (iq.view(np.float32) if datatype == "cf32_le" else iq.view(np.float64)).astype(np.longdouble).reshape(-1, 2)
     xc = x[:, 0] + 1j * x[:, 1]
     p = svc.compute_waterfall(iq, 0, nfft, datatype, 1, hop=nfft, out_fmt=sa.OUT_POW_F64)[0]
     mag = np.sqrt(p)
     M = mag.max()
-    order = np.argsort(mag)
-    weak = order[np.searchsorted(mag[order], 1e-5 * M):][:32]            # the weakest bins the dB statement covers
-    cols = np.unique(np.concatenate([order[-32:], weak, np.arange(0, nfft, nfft // 128)]))
-    k = ((cols - nfft // 2) % nfft).astype(np.longdouble)[:, None]       # column c holds bin (c - N/2) mod N   (SS:78)
-    n = np.arange(nfft, dtype=np.longdouble)[None, :]
-    two_pi = 2 * np.longdouble("3.14159265358979323846264338327950288")
-    X = (np.exp(-1j * (two_pi * ((k * n) % nfft) / nfft)) * xc[None, :]).sum(axis=1)
-    exact = np.abs(X).astype(np.float64)
+    cols = _probe_columns(mag, nfft, 1e-5)
+    exact = _exact_magnitudes(xc, cols, nfft)
     assert np.abs(mag[cols] - exact).max() <= 1e-15 * M, np.abs(mag[cols] - exact).max() / M
     sel = exact >= 1e-5 * M
     assert np.abs(20 * np.log10(mag[cols][sel]) - 20 * np.log10(exact[sel])).max() <= 1e-10
+
+
+@pytest.mark.parametrize("nfft", [256, 1024, 4096, 8192, 16384, 32768, 65536])
+@pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le", "cu8"])
+def test_fp32_lines_against_a_long_double_dft(svc, oracle, nfft, datatype):
+    """The twin for the fp32 pipeline (round 5): every fp32 kernel of the default dispatch -- the packed family, the half-line
+    kernels, the paired 65536-point kernel -- against the long-double DFT of the decoded samples (SS:40-59), no oracle and no
+    reference in between: the contract's two statements (linear on every probed bin; the noise-floor dB bound down to 1e-4 M) and
+    the regression guard on the linear one."""
+    iq = oracle.synth_iq(datatype, seed=nfft // 256 + 5, first_sample=0, n_samples=nfft)
+    if datatype == "cf32_le":
+        x = iq.view(np.float32).astype(np.longdouble).reshape(-1, 2)
+    elif datatype == "ci16_le":
+        x = iq.view(np.int16).astype(np.longdouble).reshape(-1, 2) / 32768                 # SS:44-45
+    else:
+        x = (iq.astype(np.longdouble).reshape(-1, 2) - np.longdouble(127.5)) / 128          # SS:53-54
+    xc = x[:, 0] + 1j * x[:, 1]
+    db = svc.compute_waterfall(iq, 0, nfft, datatype, 1, hop=nfft)[0].astype(np.float64)
+    mag = 10.0 ** (db / 20.0)
+    cols = _probe_columns(mag, nfft, 1e-4)
+    exact = _exact_magnitudes(xc, cols, nfft)
+    M = max(exact.max(), mag.max())
+    lin = np.abs(mag[cols] - exact).max() / (M * np.log2(nfft))
+    assert lin <= REG_LIN, "linear error %.3g M log2 N against the exact DFT (guard %.3g, contract %.3g)" % (lin, REG_LIN, FP32_LIN)
+    sel = exact >= 1e-4 * M
+    d = np.abs(db[cols][sel] - 20 * np.log10(exact[sel] + 1e-10))
+    bound = 8.686 * FP32_FLOOR * M / exact[sel] + 2e-5
+    assert np.all(d <= bound), "dB error %.3g beyond the noise-floor bound" % d.max()
+
+
+def test_degraded_twiddles_turn_the_suite_red(oracle):
+    """Mutation test of the tolerances themselves (round 5): a context whose twiddle tables have lost their four low mantissa bits
+    ("debug_twiddle_bits": one decimal digit and a bit) still PASSES the contract's linear statement with room to spare -- 4e-6 M
+    log2 N was 24 times what the kernels do -- and FAILS the regression guards.  A kernel that loses a digit cannot go unnoticed."""
+    nfft, hop, n_lines, datatype = 4096, 2048, 16, "cf32_le"
+    iq = oracle.synth_iq(datatype, seed=4242, first_sample=0, n_samples=(n_lines - 1) * hop + nfft)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines)
+    good = sa.SpectralService(0)
+    bad = sa.SpectralService(0)
+    try:
+        check_fp32(good.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop), ref, nfft, regression=True)
+        bad.set_option("debug_twiddle_bits", 4)
+        got = bad.compute_waterfall(iq, 0, nfft, datatype, n_lines, hop=hop)
+        with pytest.raises(AssertionError, match="REGRESSION guard|noise-floor bound"):
+            check_fp32(got, ref, nfft, regression=True)
+        with pytest.raises(Exception):                      # the hook is refused once a context has built a table
+            good.set_option("debug_twiddle_bits", 4)
+    finally:
+        good.close()
+        bad.close()
 
 
 # ---- values at the edges of fp32: overflow of |X|^2, underflow, NaN -------------------------------------
