@@ -39,18 +39,110 @@ def _newest_dep() -> float:
     return max(os.path.getmtime(d) for d in deps)
 
 
+# ---- ISA lint run on EVERY translation unit of EVERY library this module builds -------------------------------
+# A vector-ALU write to a data register of a buffer store wider than 8 bytes within the next two instruction slots (s_nop N
+# counts N + 1) reaches the store on gfx950 when the store has a scalar offset register: measured in spec_k_v3h.hip (round 4;
+# the last lanes of a wave left with the restored value, one run in three), not padded by LLVM's hazard recogniser, which
+# exempts stores with an SGPR offset.  The measurement applies to the toolchain named in the library's .flags stamp
+# (ROCm 7.2.0's hipcc); tools/check_store_hazard.py is the command-line form, tests/test_store_hazard.py the mutation test.
+_STORE_WAIT = 2
+
+
+def _vregs(tok):
+    import re
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def store_hazard_findings(path: str):
+    """Findings (one line each) in the device assembly `path` (hipcc -S / -save-temps)."""
+    import re
+    findings, kern, ins = [], None, []
+    for line in open(path):
+        s = line.strip()
+        if line.startswith("_Z") and ":" in line:
+            kern = line.split(":")[0]
+        if not kern or not s or s.startswith((";", ".")) or s.endswith(":"):
+            continue
+        ins.append((kern, s))
+    for i, (k, s) in enumerate(ins):
+        if not re.match(r"buffer_store_(dwordx[34]|format_xyzw?)\b", s):
+            continue
+        data = _vregs(re.split(r"[ ,]+", s)[1])
+        slots, j = 0, i + 1
+        while slots < _STORE_WAIT and j < len(ins) and ins[j][0] == k:
+            toks = re.split(r"[ ,]+", ins[j][1])
+            if toks[0] == "s_nop":
+                slots += int(toks[1], 0) + 1
+            else:
+                if toks[0].startswith("v_") and not toks[0].startswith("v_cmp") and len(toks) > 1 and _vregs(toks[1]) & data:
+                    findings.append("%s: `%s` then, %d slot(s) later, `%s`" % (k[:80], s, slots + 1, ins[j][1]))
+                slots += 1
+            j += 1
+    return findings
+
+
+def kernel_spills(path: str):
+    """{mangled kernel name: spilled vector registers} from the metadata of a device assembly file."""
+    import re
+    out, name = {}, None
+    for line in open(path):
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s*\.vgpr_spill_count:\s+(\d+)", line)
+        if m and name:
+            out[name] = int(m.group(1))
+            name = None
+    return out
+
+
 def _compile(src: str, objdir: str, extra) -> str:
-    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-    cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+    """Compile one translation unit; the device assembly hipcc leaves beside the object (-save-temps: the SAME compilation,
+    not a second one) goes through the ISA lint, and a finding fails the build."""
+    stem = os.path.splitext(src)[0]
+    obj = os.path.join(objdir, stem + ".o")
+    cmd = [_hipcc(), *FLAGS, *extra, "-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+    asm = os.path.join(objdir, "%s-hip-amdgcn-amd-amdhsa-%s.s" % (stem, ARCH))
+    if not os.path.exists(asm):
+        raise RuntimeError("no device assembly for %s (expected %s): the ISA lint cannot run" % (src, asm))
+    bad = store_hazard_findings(asm)
+    for f in os.listdir(objdir):  # the other temporaries (bitcode, preprocessed source: hundreds of MB over all units)
+        if f.startswith(stem + "-") or f.startswith(stem + ".hip-"):
+            if not f.endswith(".s") or "host" in f:
+                os.remove(os.path.join(objdir, f))
+    if bad:
+        raise RuntimeError("ISA lint (store-data hazard, build.py store_hazard_findings) on %s:\n%s" % (src, "\n".join(bad[:20])))
+    with open(os.path.join(objdir, stem + ".spills"), "w") as f:  # which kernels of this unit spill (tests/test_abi.py reads the product's)
+        for k, n in sorted(kernel_spills(asm).items()):
+            f.write("%s %d\n" % (k, n))
     return obj
 
 
+_TOOLCHAIN = None
+
+
+def _toolchain() -> str:
+    """First line of `hipcc --version` (the measurement behind the ISA lint applies to it)."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        try:
+            out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+            _TOOLCHAIN = next((l.strip() for l in out if "HIP version" in l), out[0].strip() if out else "unknown")
+        except Exception:  # noqa: BLE001
+            _TOOLCHAIN = "unknown"
+    return _TOOLCHAIN
+
+
 def _stamp(extra) -> str:
-    """What a library was built with: the product flags plus any experiment flags."""
-    return " ".join([*FLAGS, *extra])
+    """What a library was built with: the product flags plus any experiment flags, and the toolchain."""
+    return " ".join([*FLAGS, *extra]) + " | " + _toolchain() + " | isa-lint: store hazard"
 
 
 # named variants: what they are compiled with, and which translation units the flags touch (the others are taken from
@@ -171,6 +263,11 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
         raise RuntimeError("link failed:\n" + r.stderr[-4000:])
     with open(stamp_path, "w") as f:
         f.write(_stamp(extra))
+    with open(lib + ".spills", "w") as f:  # kernel -> spilled vector registers, every unit of this library
+        for o in objs:
+            sp = os.path.splitext(o)[0] + ".spills"
+            if os.path.exists(sp):
+                f.write(open(sp).read())
     if verbose:
         print("built", lib)
     return lib

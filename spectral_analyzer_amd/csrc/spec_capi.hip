@@ -730,7 +730,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             // the fall-back's intermediates: one line per workgroup (round 2 kept a 1 GiB chunk scratch for the same purpose)
             // (a quarter of the CUs: the fall-back almost never runs, and its scratch is allocated with the first large-N call
             // whether it does or not -- 64 MiB instead of 256 MiB for 65536-point fp64 lines)
-            const uint32_t solo_grid = (uint32_t)(c->n_cu >= 4 ? c->n_cu / 4 : 1);
+            // ... unless the caller ASKED for the fall-back ("large_team" = 3): then it does all the work and gets every CU
+            const uint32_t solo_grid = c->opt_large_team == 3 ? (uint32_t)c->n_cu : (uint32_t)(c->n_cu >= 4 ? c->n_cu / 4 : 1);
             if (c->opt_large_team != 2 && (st = grow(c, &c->scratch, &c->scratch_bytes, (size_t)solo_grid * per_line)) != SPEC_OK) return st;
             for (uint64_t done = 0; done < n_lines;) {
                 const uint64_t nl = n_lines - done < 0x40000000ull ? n_lines - done : 0x40000000ull;  // 32-bit line index
@@ -1248,6 +1249,10 @@ static spec_status multi_shard(spec_ctx *c, spec_ctx *root, bool is_root, const 
                                uint64_t src_bytes, uint64_t src_off, spec_dtype dt, uint32_t nfft, uint32_t hop,
                                uint64_t l0, uint64_t l1, spec_window window, spec_out_fmt out_fmt, void *out,
                                int out_on_device, uint32_t n_chunks) {
+    // what spec_get_option reports is about THIS call: a context that sends nothing now (host tile, consumer, empty shard) must
+    // not keep the previous call's "verified" count or copy path
+    c->multi_verified = 0;
+    c->multi_peer_access = -1;
     if (l1 <= l0) return SPEC_OK;
     const uint64_t bps = spec_bytes_per_sample(dt), out_esz = out_fmt >= SPEC_OUT_DB20_F64 ? 8 : 4;
     const uint64_t row_bytes = (uint64_t)nfft * out_esz;
@@ -1821,6 +1826,8 @@ spec_status spec_welch_psd_multi(spec_ctx *const *ctx, uint32_t n_ctx, const voi
             status[r] = welch_impl(c, iq[0], 0, n_bytes[0], start_byte + a * psd_stride_bytes, psd_stride_bytes, np, dt, nfft, hop,
                                    n_seg, window, scaling, fs, db, nullptr, dest, out_on_device, false);
         }
+        c->multi_verified = 0;        // (about THIS call, as in multi_shard)
+        c->multi_peer_access = -1;
         if (status[r] != SPEC_OK || !out_on_device) return;
         Enter g(c);
         hipError_t e = hipSuccess;

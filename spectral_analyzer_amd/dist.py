@@ -155,10 +155,14 @@ def chunk_checksums(rows: torch.Tensor, first_line: int, bounds) -> torch.Tensor
     point), independent of how the sum is split up, and sensitive to a row that is missing, stale or in the wrong place."""
     bits = rows.view(torch.int32 if rows.element_size() == 4 else torch.int64)
     out = torch.zeros(len(bounds), dtype=torch.int64, device=rows.device)
-    for j, (a, b) in enumerate(bounds):
-        if b > a:
-            w = torch.arange(a + 1, b + 1, dtype=torch.int64, device=rows.device)
-            out[j] = (bits[a - first_line:b - first_line].to(torch.int64).sum(dim=1) * w).sum()
+    block = max(1, (64 << 20) // max(1, rows.shape[1] * 8))   # rows per step: the widened int64 copy stays at 64 MiB (ADVICE r04:
+    for j, (a, b) in enumerate(bounds):                        # a whole chunk at bench sizes was 2 GB on the root)
+        acc = torch.zeros((), dtype=torch.int64, device=rows.device)
+        for r0 in range(a, b, block):
+            r1 = min(b, r0 + block)
+            w = torch.arange(r0 + 1, r1 + 1, dtype=torch.int64, device=rows.device)
+            acc += (bits[r0 - first_line:r1 - first_line].to(torch.int64).sum(dim=1) * w).sum()   # (wraps modulo 2^64 either way)
+        out[j] = acc
     return out
 
 

@@ -120,3 +120,60 @@ def test_jni_shim_covers_every_java_native_method():
         defined = set(re.findall(r"JNICALL %s\((native\w+)\)" % macro, shim))
         assert declared and declared == defined, (cls, declared ^ defined)
     assert "Java_net_kcundercover_spectral_1analyzer_services_ExtractDownConvertService_" in shim
+
+
+# ---- the build: variant names, the ISA lint that runs inside it, the headline kernels' registers (round 5) ------------------
+def test_build_variant_names_are_unique():
+    """Round 4 lost a variant to a dictionary key defined twice; the table is built by a function that refuses that."""
+    from spectral_analyzer_amd import build
+    assert len(build.VARIANTS) >= 10
+    with pytest.raises(ValueError, match="defined twice"):
+        build._unique([("a", ([], [])), ("b", ([], [])), ("a", ([], []))])
+    for name, (flags, units) in build.VARIANTS.items():
+        assert units and all(u in build.SOURCES for u in units), name
+
+
+def test_every_library_build_ran_the_isa_lint():
+    """The store-data hazard lint (build.py store_hazard_findings) runs on the device assembly of every translation unit of
+    every library build.py produces and fails the build on a finding; the stamp beside the library says so and names the
+    toolchain the measurement behind the lint applies to."""
+    from spectral_analyzer_amd import build
+    lib = build.build()
+    stamp = open(lib + ".flags").read()
+    assert "isa-lint: store hazard" in stamp and "HIP version" in stamp
+    bad = "_Zk:\n\tbuffer_store_dwordx4 v[4:7], v1, s[8:11], s0 offen\n\tv_mov_b32_e32 v5, v9\n\ts_endpgm\n"
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write(bad)
+    try:
+        assert len(build.store_hazard_findings(f.name)) == 1
+    finally:
+        os.unlink(f.name)
+
+
+def test_headline_kernels_do_not_spill():
+    """The kernels behind the bench workloads keep everything in registers (a spill inside a line loop costs a scratch round trip
+    per line: the first builds of the 65536-point pair kernel lost 10 % to eleven spilled registers).  Read from the spill report the
+    build writes beside the library; a compiler or source change that makes one of them spill fails here, not on the GPU box."""
+    import subprocess
+    from spectral_analyzer_amd import build
+    lib = build.build()
+    rows = [l.split() for l in open(lib + ".spills").read().splitlines()]
+    names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.splitlines()
+    spills = {n.replace("specgpu::(anonymous namespace)::", ""): int(r[1]) for n, r in zip(names, rows)}
+    headline = {
+        "v2_kernel<12, 4, 8, false, 0, false,": 0,     # cfg2: 4096 points, cf32, 50 % overlap
+        "v2_kernel<12, 3, 8, false, 0, false,": 0,     # cfg3: ci16
+        "v2_kernel<10, 4, 8, false, 0, false,": 0,     # cfg1
+        "v2_kernel<14, 4, 8, true, 1, false,": 0,      # cfg4: 16384-point Welch segments, 75 % overlap
+        "v2_kernel<14, 4, 16, false, 0, false,": 0,    # n16384
+        "v2h_kernel<14, 4, false, false, false>": 0,   # n32768f
+        "v2q_kernel<4, false, false>": 1,              # n65536f (one register, outside the line loop)
+        "v2q_kernel<3, false, false>": 0,              # 65536 points, ci16
+        "v3h_kernel<5, false, false, false>": 4,       # n16384d (round 4: 36 bytes of scratch per lane, DESIGN.md 4.4d)
+    }
+    for pat, allowed in headline.items():
+        hits = {k: v for k, v in spills.items() if pat in k}
+        assert hits, "no kernel matches %r" % pat
+        for k, v in hits.items():
+            assert v <= allowed, "%s spills %d vector registers (allowed %d)" % (k, v, allowed)

@@ -6,45 +6,14 @@ of the wave are stored with the new value; LLVM's hazard recogniser pads the pat
 offset register.
 
     python tools/check_store_hazard.py <file.s> [...]      exit status 1 and one line per finding
+The check itself lives in spectral_analyzer_amd/build.py (store_hazard_findings): every build of every library -- product and
+variants -- runs it on the device assembly of every translation unit and fails on a finding.
 """
-import re
+import os
 import sys
 
-WAIT = 2
-
-
-def regs(tok):
-    m = re.match(r"v\[(\d+):(\d+)\]", tok)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"v(\d+)$", tok)
-    return {int(m.group(1))} if m else set()
-
-
-def check(path):
-    findings, kern, ins = [], None, []
-    for line in open(path):
-        s = line.strip()
-        if line.startswith("_Z") and ":" in line:
-            kern = line.split(":")[0]
-        if not kern or not s or s.startswith((";", ".")) or s.endswith(":"):
-            continue
-        ins.append((kern, s))
-    for i, (k, s) in enumerate(ins):
-        if not re.match(r"buffer_store_(dwordx[34]|format_xyzw?)\b", s):
-            continue
-        data = regs(re.split(r"[ ,]+", s)[1])
-        slots, j = 0, i + 1
-        while slots < WAIT and j < len(ins) and ins[j][0] == k:
-            toks = re.split(r"[ ,]+", ins[j][1])
-            if toks[0] == "s_nop":
-                slots += int(toks[1], 0) + 1
-            else:
-                if toks[0].startswith("v_") and not toks[0].startswith("v_cmp") and len(toks) > 1 and regs(toks[1]) & data:
-                    findings.append("%s: `%s` then, %d slot(s) later, `%s`" % (k[:80], s, slots + 1, ins[j][1]))
-                slots += 1
-            j += 1
-    return findings
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from spectral_analyzer_amd.build import store_hazard_findings as check  # noqa: E402  (ONE implementation: the build runs it on every unit)
 
 
 def main():
