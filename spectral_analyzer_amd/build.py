@@ -34,7 +34,8 @@ def _hipcc() -> str:
 
 
 def _newest_dep() -> float:
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not os.path.isdir(os.path.join(CSRC, f))]
+    deps += [os.path.join(CSRC, "experiments", f) for f in os.listdir(os.path.join(CSRC, "experiments"))]
     deps.append(os.path.join(HERE, "..", "include", "specgpu.h"))
     return max(os.path.getmtime(d) for d in deps)
 
@@ -100,12 +101,28 @@ def kernel_spills(path: str):
     return out
 
 
+# experiment variants whose flags concern the team kernel compile the frozen experiment copy of it (csrc/experiments/): the
+# product file no longer carries that code
+EXPERIMENT_SOURCE = {"spec_k_team.hip": os.path.join("experiments", "spec_k_team_exp.hip")}
+_TEAM_EXPERIMENT_FLAGS = ("-DSPEC_TEAM_WA", "-DSPEC_ABL_TEAM", "-DSPEC_ABL_WA", "-DSPEC_TEAM_PROF", "-DSPEC_TEAM_STRICT_WAITS",
+                          "-DSPEC_TEAM_SINGLE_STORES", "-DSPEC_TEAM_NO_STRIPX")
+
+
+def _source_for(src: str, extra) -> str:
+    if src in EXPERIMENT_SOURCE and any(f.startswith(_TEAM_EXPERIMENT_FLAGS) for f in extra):
+        return EXPERIMENT_SOURCE[src]
+    return src
+
+
 def _compile(src: str, objdir: str, extra) -> str:
     """Compile one translation unit; the device assembly hipcc leaves beside the object (-save-temps: the SAME compilation,
     not a second one) goes through the ISA lint, and a finding fails the build."""
     stem = os.path.splitext(src)[0]
     obj = os.path.join(objdir, stem + ".o")
-    cmd = [_hipcc(), *FLAGS, *extra, "-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
+    real = _source_for(src, extra)
+    if real != src:  # (same object name; the temporaries carry the real file's stem)
+        stem = os.path.splitext(os.path.basename(real))[0]
+    cmd = [_hipcc(), *FLAGS, *extra, "-I" + CSRC, "-save-temps=obj", "-c", os.path.join(CSRC, real), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
@@ -119,7 +136,7 @@ def _compile(src: str, objdir: str, extra) -> str:
                 os.remove(os.path.join(objdir, f))
     if bad:
         raise RuntimeError("ISA lint (store-data hazard, build.py store_hazard_findings) on %s:\n%s" % (src, "\n".join(bad[:20])))
-    with open(os.path.join(objdir, stem + ".spills"), "w") as f:  # which kernels of this unit spill (tests/test_abi.py reads the product's)
+    with open(os.path.splitext(obj)[0] + ".spills", "w") as f:  # which kernels of this unit spill (tests/test_abi.py reads the product's)
         for k, n in sorted(kernel_spills(asm).items()):
             f.write("%s %d\n" % (k, n))
     return obj

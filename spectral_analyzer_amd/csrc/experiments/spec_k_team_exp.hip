@@ -1,3 +1,6 @@
+// experiments/spec_k_team_exp.hip -- the team kernel WITH its experiments, frozen at the end of round 4 (round 5 split it from
+// csrc/spec_k_team.hip, which is this file with every experiment macro undefined and the dead branches removed; the two compile
+// to the same instructions).  Built only into variant libraries (build.py: tWA*, tOLDa, tPROF; tools/r04_wa*.sh, tools/team_prof.py).
 // spec_k_team.hip -- four-step FFT for lines longer than the LDS holds (fp32: nfft >= 32768, fp64:
 // nfft >= 16384; BASELINE configs[4] is 65536-point cf64) with the intermediate kept in the XCD's L2.
 //
@@ -32,12 +35,6 @@
 //   * every spin is bounded (wall clock): on a timeout -- the grid was not co-resident, e.g. the GPU is
 //     shared -- the workgroup raises the abort word and every workgroup leaves; the host then runs the
 //     two-launch path of spec_k_large.hip (guarded kernels that start only when the abort word is set).
-//
-// Round 5: this file is the kernel that SHIPS.  The round-2 ... round-4 experiments that used to live here behind SPEC_TEAM_WA*
-// (wave-autonomous column side), SPEC_ABL_TEAM_* (ablations), SPEC_TEAM_PROF (phase counters, event trace) and a few one-off
-// switches are kept, frozen, in csrc/experiments/spec_k_team_exp.hip; the variant libraries tWA*, tOLDa, tPROF build from that
-// file (build.py), the product and the teamvar library (SPEC_TEAM_VARIANTS: the 256- / 1024-thread geometries under test) from
-// this one.  With no experiment macro defined the two files compile to the same instructions (checked when they were split).
 #include <type_traits>
 
 #include "spec_kernels.h"
@@ -115,6 +112,25 @@ __device__ __forceinline__ bool team_wait(const uint32_t *ctr, uint32_t target, 
     return ok != 0;
 }
 
+// The same wait for ONE wave (wave-autonomous sides, SPEC_TEAM_WA): lane 0 polls, the verdict is broadcast; no barrier.
+__device__ __forceinline__ bool wave_wait(const uint32_t *ctr, uint32_t target, uint32_t *sync) {
+    int ok = 1;
+    if ((threadIdx.x & 63) == 0) {
+        if ((int32_t)(ld_sc1(ctr) - target) < 0) {
+            const long long t0 = wall_clock64();
+            uint32_t spins = 0;
+            while ((int32_t)(ld_sc1(ctr) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 31u) == 0 && (ld_sc1(sync + TS_ABORT) != 0 || wall_clock64() - t0 > TEAM_SPIN_LIMIT)) {
+                    ok = 0;
+                    break;
+                }
+            }
+            if (!ok) __hip_atomic_store(sync + TS_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
 
 template <typename R> __device__ __forceinline__ void ctw(cx<R> &u, const cx<R> w) { u = cmul(u, w); }
 
@@ -213,7 +229,54 @@ template <typename R, int L, int WG> __device__ __forceinline__ void xload(cx<R>
 // instructions of this wave are done", N a LOWER bound of the instructions issued since -- and reads its own
 // lanes back with ds_read_b128.  The waits carry a "memory" clobber: no LDS read moves above them.  LDS-DMA moves
 // 4 or 16 bytes per lane: a cx<double> each, or two neighbouring cx<float> of one row (dma_coords in the kernel).
-template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#ifdef SPEC_TEAM_STRICT_WAITS  // debugging aid: every counted wait becomes vmcnt(0)
+#define VM_N(N) 0
+#else
+#define VM_N(N) (N)
+#endif
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_N(N)) : "memory"); }
+
+// development aid (variant builds with -DSPEC_TEAM_PROF): lane 0 of every workgroup adds up shader-clock cycles
+// spent in its waits; eight 64-bit words per workgroup behind the synchronisation block
+#ifdef SPEC_TEAM_PROF
+#define PROF_DECL unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pf_t = 0; (void)pf_t
+#define PROF_T0() (pf_t = __builtin_readcyclecounter())
+#define PROF_ADD(k) (pf[k] += __builtin_readcyclecounter() - pf_t)
+#define PROF_INC(k) (pf[k] += 1)
+#define PROF_PH(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); ph[k] += n__ - ph_t; ph_t = n__; } while (0)
+#define PROF_OUT(role)                                                                                          \
+    do {                                                                                                        \
+        if (threadIdx.x == 0) {                                                                                 \
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(a.sync + TEAM_SYNC_WORDS) + 16ull * blockIdx.x; \
+            pf[7] = (unsigned long long)(role) | ((unsigned long long)team << 8) | ((unsigned long long)my_lines << 32);   \
+            {                                                                                                   \
+                uint32_t hw__, xc__;                                                                            \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw__));                             \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc__));                            \
+                pf[6] = hw__ | ((unsigned long long)xc__ << 32);                                                \
+            }                                                                                                   \
+            for (int k = 0; k < 8; ++k) o[k] = pf[k];                                                           \
+            for (int k = 0; k < 8; ++k) o[8 + k] = ph[k];                                                       \
+        }                                                                                                       \
+    } while (0)
+// event trace of ONE team (team 0), lines TRACE_L0 .. TRACE_L0 + 31, lane 0 of every member workgroup: wall-clock ticks
+// (100 MHz, the same clock on every CU) behind the per-workgroup words -- tools/team_trace.py prints the hand-offs
+#define TRACE_L0 1000u
+#define TRACE(ev, i)                                                                                                  \
+    do {                                                                                                              \
+        if (threadIdx.x == 0 && team == 0 && (i) >= TRACE_L0 && (i) < TRACE_L0 + 32u)                                   \
+            (reinterpret_cast<unsigned long long *>(a.sync + TEAM_SYNC_WORDS) + 16384ull)[((size_t)member * 32u + ((i) - TRACE_L0)) * 8u + (ev)] = \
+                (unsigned long long)wall_clock64();                                                                   \
+    } while (0)
+#else
+#define TRACE(ev, i) (void)0
+#define PROF_DECL (void)0
+#define PROF_T0() (void)0
+#define PROF_ADD(k) (void)0
+#define PROF_INC(k) (void)0
+#define PROF_PH(k) (void)0
+#define PROF_OUT(role) (void)0
+#endif
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byte address of a pointer into shared memory
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
@@ -273,6 +336,9 @@ template <typename R> __device__ __forceinline__ cx<R> ld_slot(__amdgpu_buffer_r
 }
 
 template <typename R> __device__ __forceinline__ void st_slot(cx<R> *p, cx<R> v) {  // plain store: stays in L2
+#ifdef SPEC_ABL_TEAM_NOSLOT  // ablation: the value stays alive, nothing is stored
+    if (v.x != (R)1.2345e-30) return;
+#endif
     if constexpr (sizeof(R) == 8) {
         typedef double d2 __attribute__((ext_vector_type(2)));
         *reinterpret_cast<d2 *>(p) = d2{v.x, v.y};
@@ -282,13 +348,25 @@ template <typename R> __device__ __forceinline__ void st_slot(cx<R> *p, cx<R> v)
     }
 }
 
+#ifdef SPEC_ABL_TEAM_NOSTORE
+constexpr int TEAM_NST = 0;
+#else
+#ifdef SPEC_TEAM_SINGLE_STORES
+constexpr int TEAM_NST = TE;      // output stores per thread and line: one instruction per bin, every format
+#else
 constexpr int TEAM_NST = TE / 2;  // output stores per thread and line: one instruction per pair of bins, every format
+#endif
+#endif
 
 // value of one bin (SS:76-82) in the arithmetic of the pipeline
 template <typename R, int FMT> __device__ __forceinline__ R bin_value(cx<R> z, const double *dbt) {
+#ifdef SPEC_ABL_TEAM_NOEPI
+    return z.x;
+#else
     constexpr bool dbf = FMT == OUT_DB20_F32 || FMT == OUT_DB20_F64;
     if constexpr (sizeof(R) == 4) return dbf ? db20(z) : z.x * z.x + z.y * z.y;
     else return dbf ? db20_tab(z, dbt) : __builtin_fma(z.x, z.x, z.y * z.y);
+#endif
 }
 // the value of the neighbouring lane (lane ^ 1): DPP quad permutation, no LDS
 __device__ __forceinline__ float lane_swap1(float x) {
@@ -307,6 +385,12 @@ template <typename T> __device__ __forceinline__ void st_pair(T *p, T lo, T hi) 
 
 // one bin of the result (SS:76-82), non-temporal: written once, never read by this launch
 template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *out, uint64_t idx, cx<R> z, const double *dbt) {
+#ifdef SPEC_ABL_TEAM_NOSTORE
+    if (z.x == (R)1.2345e-30) static_cast<float *>(out)[idx & 1023] = 0.0f;  // never true: keeps z alive
+#elif defined(SPEC_ABL_TEAM_NOEPI)
+    if constexpr (FMT >= OUT_DB20_F64) __builtin_nontemporal_store((double)z.x, static_cast<double *>(out) + idx);
+    else __builtin_nontemporal_store((float)z.x, static_cast<float *>(out) + idx);
+#else
     if constexpr (sizeof(R) == 4) {
         const float r = FMT == OUT_DB20_F32 ? db20(z) : z.x * z.x + z.y * z.y;
         __builtin_nontemporal_store(r, static_cast<float *>(out) + idx);
@@ -316,6 +400,7 @@ template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *ou
         if constexpr (FMT >= OUT_DB20_F64) __builtin_nontemporal_store(r, static_cast<double *>(out) + idx);
         else __builtin_nontemporal_store((float)r, static_cast<float *>(out) + idx);
     }
+#endif
 }
 
 // Dynamic LDS of one workgroup.  Pipelined loads: 256 bytes for the polled counter word, then the landing
@@ -325,7 +410,12 @@ template <typename R, int FMT> __device__ __forceinline__ void emit_bin(void *ou
 // DENSE: two workgroups per CU (four waves per SIMD, 128 registers each) that hide latency by occupancy: no
 // landing strips, the plain forms of both sides.
 template <typename R, int L1, int L2, int WG, bool DENSE> struct TeamLds {
+#ifdef SPEC_TEAM_WA
+    // wave-autonomous column side: line buffers padded by one element per eight (WSL = M + M / 8 elements per column)
+    static constexpr size_t A = (size_t)TP<L1, WG>::C * (TP<L1, WG>::M + TP<L1, WG>::M / 8) + TP<L1, WG>::M;
+#else
     static constexpr size_t A = (size_t)TP<L1, WG>::C * TP<L1, WG>::SL + TP<L1, WG>::M;
+#endif
     static constexpr size_t B = (size_t)TP<L2, WG>::C * TP<L2, WG>::SL + TP<L2, WG>::M;
     static constexpr size_t MAIN = A > B ? A : B;
     static constexpr bool PIPE = !DENSE;
@@ -353,10 +443,29 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     __shared__ int s_flag, s_next;
     __shared__ uint32_t s_info[4];
     __shared__ uint32_t s_arrive;  // column side: waves whose stores of the pending line are in L2 (monotonic)
+    __shared__ uint32_t s_arrive_slot[TEAM_RING_MAX];  // wave-autonomous column side: the same count per ring slot
     constexpr uint32_t WAVES = WG / 64;
+#ifndef SPEC_TEAM_WA_DEEP
+#define SPEC_TEAM_WA_DEEP 1  // wave-autonomous column side at 50 % overlap: requests two lines ahead
+#endif
+#ifndef SPEC_TEAM_WA_ANN
+#define SPEC_TEAM_WA_ANN 0  // where a wave of the wave-autonomous column side waits for its previous line's stores and
+#endif                      // announces: 0 behind pass 0's exchange write, 1 behind pass 1, 2 behind the whole transform
+#ifndef SPEC_TEAM_WA_LD
+#define SPEC_TEAM_WA_LD 2  // cache policy of the wave-autonomous column side's requests (glds16): 0 nt, 2 plain
+#endif
+#ifdef SPEC_TEAM_WA
+    // wave-autonomous column side (fp64 lines, samples as they are in memory): every WAVE announces its own two columns
+    constexpr bool WA_COL = sizeof(R) == 8 && DIRECT && !DENSE && WG == 512;
+#else
+    constexpr bool WA_COL = false;
+#endif
     constexpr uint32_t APT = 1u;  // announcements (adds to doneA) per column tile and line (one per WAVE was tried: 128 adds per
                                   // line and team on one L2 word -- 35 ms per cfg5 step against 13.3)
     double *s_dbt = reinterpret_cast<double *>(smem + LD::DBT_OFF);
+#ifdef SPEC_TEAM_PROF
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t = 0;  // phase stamps of lane 0 (tools/team_prof.py)
+#endif
     cx<R> *lds = reinterpret_cast<cx<R> *>(smem + LD::LAND_BYTES);  // line buffers + table
     const int tid = threadIdx.x;
     uint32_t *sync = a.sync;
@@ -369,6 +478,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     // would still come out in equal numbers, only the pairing would be imperfect.
     constexpr bool PAIRED = WG == 256;
     if (tid == 0) s_arrive = 0;
+    if (tid < TEAM_RING_MAX) s_arrive_slot[tid] = 0;
     if (tid == 0) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -456,6 +566,7 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
     // between the two precisions, not what is read back.
     const uint32_t wave = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63;
     constexpr int EPL = 16 / (int)sizeof(cx<R>);  // elements per lane and LDS-DMA instruction
+    constexpr int NI = TE / EPL;                   // instructions per tile and wave, 1 KiB of strip each
     uint32_t *pland = reinterpret_cast<uint32_t *>(smem);
     cx<R> *land = reinterpret_cast<cx<R> *>(smem + 256 + (size_t)wave * TE * 64 * sizeof(cx<R>));
     // which (row within the tile's thread grid, column, m offset) a lane REQUESTS for a tile C columns wide
@@ -471,10 +582,14 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 
     if (member < NT) {
         // ================= column side: tile of C columns, N1-point transforms over n1 =====================
+#ifdef SPEC_ABL_TEAM_NOA
+        return;
+#endif
         const uint32_t c0 = member * PA::C;
         const int q0 = tid % PA::C, t0 = tid / PA::C;  // loads: columns fastest (contiguous samples)
         const int t1 = tid % PA::T, q1 = tid / PA::T;  // stores: k1 fastest (contiguous intermediate)
-        cx<R> *tab = lds + (size_t)PA::C * PA::SL;
+        constexpr int WSL = PA::M + PA::M / 8;  // wave-autonomous form: padded column buffers (below)
+        cx<R> *tab = lds + (size_t)PA::C * (WA_COL ? WSL : PA::SL);
         for (int e = tid; e < N1; e += WG) tab[e] = static_cast<const cx<R> *>(a.tw1)[e];
         const R *__restrict__ win = static_cast<const R *>(a.win);
         // inter-step twiddle W_N^(n2 k1), k1 = t1 + m T: W^(n2 t1) (W^(n2 T))^m, recurrence in fp64
@@ -502,8 +617,10 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             twr.load(t1, tab);
         }
         auto finish = [&](cx<R> (&v)[TE]) {
+#ifndef SPEC_ABL_TEAM_NOFFT
             if constexpr (TWREG) twr.pass2(v);
             else pass2<R, L1, WG>(v, t1, tab);
+#endif
             if constexpr (TW_LINE_INV) {
 #pragma unroll
                 for (int m = 0; m < TE; ++m) v[m] = cmul(v[m], wtw[m]);
@@ -517,6 +634,246 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 }
             }
         };
+        if constexpr (WA_COL) {
+            if (win == nullptr) {
+                // ---- wave-autonomous form (round 4) ----------------------------------------------------------------------
+                // The workgroup's 16 columns are dealt to its 8 waves, two each; a column's 32 threads are one half of a
+                // wave, so ALL of a line's exchanges stay inside the wave and nothing in the line loop is a workgroup
+                // barrier: the eight waves of a CU drift apart and fill each other's LDS, vector-memory and arithmetic
+                // phases instead of walking them in lock step (one workgroup's waves in step leave the vector
+                // ALU 0.36 busy).  Every wave requests its own two columns (32- or 64-byte pieces: CPW adjacent lanes = one row of its
+                // columns), keeps line i + 1's upper half in flight behind line i's transform, stores and announces its own
+                // columns, polls the ring for itself (a word of its own), and the last wave to see its stores done announces the tile.
+                constexpr uint32_t CPW = 64u / PA::T;                      // columns per wave: 2 (256-point columns) or 4 (128-point)
+                const uint32_t wq = lane / PA::T, wt = lane % PA::T;       // transform role: column wq of the wave's, butterfly index wt
+                const uint32_t ncol = c0 + CPW * wave + wq;                // n2 of this lane's column
+                cx<R> *colbuf = lds + (size_t)(CPW * wave + wq) * WSL;     // that column's line buffer: this wave's alone
+                // Exchanges in the (column, butterfly) lane order: a column's threads are NEIGHBOURS, so pass 0's writes
+                // (element 8 t + r: lanes 128 bytes apart) would all hit the same four banks -- measured 35 ms per cfg5
+                // step.  One pad element per eight, index a -> a + (a >> 3): eight neighbouring lanes then cover all 32
+                // banks once on every write and read of both exchanges.
+                auto pad8 = [](int a) { return a + (a >> 3); };
+                auto wstore0 = [&](const cx<R> (&x)[TE]) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) colbuf[9 * (int)wt + r] = x[r];            // pad8(8 t + r) = 9 t + r
+                };
+                auto wstore1 = [&](const cx<R> (&x)[TE]) {
+                    const int k = (int)wt & 7, j = ((int)wt - k) * 8 + k;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) colbuf[pad8(j) + 9 * r] = x[r];            // pad8(j + 8 r): (j + 8 r) >> 3 = (j >> 3) + r
+                };
+                auto wload = [&](cx<R> (&x)[TE]) {
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) x[m] = colbuf[pad8((int)wt + m * PA::T)];
+                };
+#ifdef SPEC_ABL_WA_COALESCED  // ablation (results WRONG by construction): the same request volume as 256-byte rows -- 16 neighbouring
+                                   // lanes = the workgroup's 16 columns of one row -- to price the 32-byte pieces of the real thing
+                const uint32_t dk = 4u * wave + lane / 16u, dcol = c0 + lane % 16u;
+#else
+                const uint32_t dk = lane / CPW, dcol = c0 + CPW * wave + lane % CPW;  // request role: row dk (+ T m) of column dcol
+#endif
+                constexpr int NLD = HALF ? NEWH : TE;
+                auto issue_rows = [&](uint32_t line, auto first_tag, auto end_tag) {
+                    constexpr int FIRST = decltype(first_tag)::value, END = decltype(end_tag)::value;
+                    const uint8_t *src = a.iq + (uint64_t)line * a.hop * sizeof(cx<R>);
+#pragma unroll
+                    for (int m = FIRST; m < END; ++m)
+                        glds16<SPEC_TEAM_WA_LD>(src + (uint64_t)((dk + (uint32_t)PA::T * m) * N2 + dcol) * sizeof(cx<R>), land_addr + 1024u * m);
+                };
+                auto issue_next = [&](uint32_t i_next) {
+                    const uint32_t ic = i_next < my_lines ? i_next : my_lines - 1;  // tail: a valid line again, unused
+                    const uint32_t ln = line_of(ic);
+                    if constexpr (HALF) {
+                        if (!follows(ic)) issue_rows(ln, std::integral_constant<int, 0>{}, std::integral_constant<int, NEWH>{});
+                        issue_rows(ln, std::integral_constant<int, NEWH>{}, std::integral_constant<int, TE>{});
+                    } else {
+                        issue_rows(ln, std::integral_constant<int, 0>{}, std::integral_constant<int, TE>{});
+                    }
+                };
+                const cx<R> *mine = land + CPW * wt + wq;                  // element (row wt + T m) of my column at mine[64 m]
+                __syncthreads();  // table visible (set-up: the only workgroup barrier of this side)
+                PassTw<R, L1, WG> wtw;
+                wtw.load((int)wt, tab);
+                const cx<double> ww0 = twn[ncol * wt], wwstep = twn[ncol * (uint32_t)PA::T];
+                cx<R> cur[TE];
+                issue_rows(line_of(0), std::integral_constant<int, 0>{}, std::integral_constant<int, TE>{});
+                vm_wait<0>();
+#pragma unroll
+                for (int m = 0; m < TE; ++m) cur[m] = mine[64 * m];
+                wave_sync();
+                uint32_t pending = NONE;
+#if SPEC_TEAM_WA_DEEP
+                if constexpr (HALF) {
+                    if (blk == 0) {
+                        // ---- 50 % overlap, contiguous lines: the new upper half of a line is requested TWO lines ahead.  One line
+                        // ahead, a wave's loop time is bounded by the memory latency (its stores and the next requests sit in one
+                        // in-order queue, and the next line cannot start before they are back: measured 1.9 us per line with the
+                        // slot stores removed, 3.9 with them, against 1.3 us of arithmetic).  The strip is half empty at 50 %
+                        // overlap: lines alternate between its two halves (instruction slots 4 p .. 4 p + 3, p = line & 1).
+                        auto issue_upper = [&](uint32_t i_line) {
+                            const uint32_t ic = i_line < my_lines ? i_line : my_lines - 1;  // tail: a valid line again, unused
+                            const uint8_t *src = a.iq + (uint64_t)line_of(ic) * a.hop * sizeof(cx<R>);
+                            const uint32_t base = land_addr + 1024u * NEWH * (i_line & 1u);
+#pragma unroll
+                            for (int m = 0; m < NEWH; ++m)
+                                glds16<SPEC_TEAM_WA_LD>(src + (uint64_t)((dk + (uint32_t)PA::T * (m + NEWH)) * N2 + dcol) * sizeof(cx<R>), base + 1024u * m);
+                        };
+                        issue_upper(1);
+                        issue_upper(2);
+#ifdef SPEC_ABL_TEAM_NOSLOT
+                        constexpr int YOUNGER = NEWH;           // ablation build: no slot stores in the queue
+#else
+                        constexpr int YOUNGER = TE + NEWH;      // behind line i + 1's requests: the stores of line i - 1, line i + 2's requests
+#endif
+                        for (uint32_t i = 0; i < my_lines; ++i) {
+                            const uint32_t slot = i % a.ring, round = i / a.ring;
+                            cx<R> v[TE];
+#pragma unroll
+                            for (int m = 0; m < TE; ++m) v[m] = cur[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
+                            dft8(v);
+#endif
+                            wstore0(v);
+                            wave_sync();
+                            wload(v);
+                            wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                            wtw.pass1(v);
+#endif
+                            wstore1(v);
+                            wave_sync();
+                            wload(v);
+                            wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                            wtw.pass2(v);
+#endif
+                            {   // inter-step twiddle W_N^(n2 k1), k1 = wt + T m: recurrence in fp64
+                                cx<double> w = ww0;
+#pragma unroll
+                                for (int m = 0; m < TE; ++m) {
+                                    v[m] = cmul(v[m], w);
+                                    w = cmul(w, wwstep);
+                                }
+                            }
+                            // line i + 1's upper half was requested two lines ago; what is younger may stay in flight
+                            if (i == 0) vm_wait<NEWH>();
+                            else vm_wait<YOUNGER>();
+                            {
+                                const cx<R> *up = mine + 64 * NEWH * ((i + 1) & 1u);
+#pragma unroll
+                                for (int m = 0; m < NEWH; ++m) { cur[m] = cur[m + NEWH]; cur[m + NEWH] = up[64 * m]; }
+                            }
+                            wave_sync();
+                            // the stores of line i - 1 (older than line i + 2's requests) have had a whole line: announce it
+                            vm_wait<NEWH>();
+                            if (lane == 0 && pending != NONE && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((i - 1) / a.ring + 1))
+                                __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                            if (round != 0 && (pending == NONE || (int32_t)(pland[2u * wave + (i & 1u)] - NT * round) < 0) &&
+                                !wave_wait(ring + 32 * slot + 16, NT * round, sync)) return;
+#endif
+                            {
+                                const uint32_t word = __builtin_amdgcn_readfirstlane(pland_addr + 8u * wave + 4u * ((i + 1) & 1u));
+                                if (lane == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, word);  // before the stores
+                            }
+                            cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)ncol * N1;
+                            asm volatile("" ::: "memory");
+#pragma unroll
+                            for (int m = 0; m < TE; ++m) st_slot<R>(dst + wt + m * PA::T, v[m]);
+                            asm volatile("" ::: "memory");  // the loads below stay behind the stores above
+                            pending = slot;
+                            issue_upper(i + 3);             // into the half of the strip just read
+                        }
+                        vm_wait<0>();
+                        if (lane == 0 && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((my_lines - 1) / a.ring + 1))
+                            __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
+                }
+#endif
+                issue_next(1);
+                for (uint32_t i = 0; i < my_lines; ++i) {
+                    const uint32_t slot = i % a.ring, round = i / a.ring;
+                    cx<R> v[TE];
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) v[m] = cur[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    dft8(v);
+#endif
+                    wstore0(v);
+                    wave_sync();
+                    auto announce = [&]() {
+                        // the LAST wave of the workgroup to see its stores of the pending line (i - 1) done announces the tile.
+                        // Counted per ring slot: the waves are not in step, but nobody arrives for line j + ring before line j
+                        // has been announced (its slot is not free before that)
+                        if (lane == 0 && pending != NONE && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((i - 1) / a.ring + 1))
+                            __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    };
+#if SPEC_TEAM_WA_ANN == 0
+                    // the previous line's stores have had this long: wait for them, not for the NLD loads behind them
+                    vm_wait<NLD>();
+                    announce();
+#endif
+                    wload(v);
+                    wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    wtw.pass1(v);
+#endif
+#if SPEC_TEAM_WA_ANN == 1
+                    vm_wait<NLD>();
+                    announce();
+#endif
+                    wstore1(v);
+                    wave_sync();
+                    wload(v);
+                    wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
+                    wtw.pass2(v);
+#endif
+                    {   // inter-step twiddle W_N^(n2 k1), k1 = wt + T m: recurrence in fp64
+                        cx<double> w = ww0;
+#pragma unroll
+                        for (int m = 0; m < TE; ++m) {
+                            v[m] = cmul(v[m], w);
+                            w = cmul(w, wwstep);
+                        }
+                    }
+                    vm_wait<0>();  // line i + 1's rows, requested a whole line ago
+#if SPEC_TEAM_WA_ANN == 2
+                    announce();
+#endif
+                    if (HALF && follows(i + 1 < my_lines ? i + 1 : my_lines - 1)) {
+#pragma unroll
+                        for (int m = 0; m < NEWH; ++m) { cur[m] = cur[m + NEWH]; cur[m + NEWH] = mine[64 * (m + NEWH)]; }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < TE; ++m) cur[m] = mine[64 * m];
+                    }
+                    wave_sync();
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                    // is the slot free?  The poll was taken one line earlier (this wave's own word, parity i & 1; it landed
+                    // before the vm_wait<0> above); "not yet" is a blocking wait of this wave alone
+                    if (round != 0 && (pending == NONE || (int32_t)(pland[2u * wave + (i & 1u)] - NT * round) < 0) &&
+                        !wave_wait(ring + 32 * slot + 16, NT * round, sync)) return;
+#endif
+                    {
+                        const uint32_t word = __builtin_amdgcn_readfirstlane(pland_addr + 8u * wave + 4u * ((i + 1) & 1u));
+                        if (lane == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, word);  // before the stores
+                    }
+                    cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)ncol * N1;
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int m = 0; m < TE; ++m) st_slot<R>(dst + wt + m * PA::T, v[m]);
+                    asm volatile("" ::: "memory");  // the loads below stay behind the stores above
+                    pending = slot;
+                    issue_next(i + 2);
+                }
+                vm_wait<0>();
+                if (lane == 0 && atomicAdd(&s_arrive_slot[pending], 1u) + 1 == WAVES * ((my_lines - 1) / a.ring + 1))
+                    __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
         if constexpr (DIRECT && LD::PIPE) {
             if (win == nullptr) {
                 // ---- pipelined form: samples are cx<double> in memory, no window ----------------------------------
@@ -558,19 +915,32 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 issue_next(1);
                 __syncthreads();  // table visible
                 uint32_t pending = NONE;  // ring slot whose stores are issued but not yet announced
+                PROF_DECL;
+#ifdef SPEC_TEAM_PROF
+                const unsigned long long pf_begin = __builtin_readcyclecounter();
+#endif
                 for (uint32_t i = 0; i < my_lines; ++i) {
                     const uint32_t slot = i % a.ring, round = i / a.ring;
+                    TRACE(0, i);
                     cx<R> v[TE];
 #pragma unroll
                     for (int m = 0; m < TE; ++m) v[m] = cur[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
                     dft8(v);
+#endif
                     xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
                     // the previous line's stores (and the poll before them) have had this long: wait for them, not
                     // for the NLD loads issued behind them; the last wave to see its stores done announces the line
+                    PROF_T0();
                     vm_wait<NLD>();
                     if (lane == 0 && pending != NONE && atomicAdd(&s_arrive, 1u) + 1 == WAVES * i)
                         __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    PROF_ADD(1);
+                    TRACE(1, i);
+                    PROF_T0();
                     __syncthreads();
+                    PROF_ADD(4);
+                    TRACE(2, i);
                     // was the slot free when the poll was taken?  (first lines: nobody has used it yet.)  The poll of
                     // line i landed in word i & 1 before wave 0 came to the barrier above; that word is rewritten two
                     // lines on
@@ -579,14 +949,19 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     // wave reads and writes only the rows of its own columns -- the second exchange needs no barrier
                     xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
                     wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
                     if constexpr (TWREG) twr.pass1(v);
                     else pass1<R, L1, WG>(v, t1, tab);
+#endif
                     xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
                     wave_sync();
                     xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
                     finish(v);
+                    TRACE(3, i);
                     // cur <- line i + 1: its rows were requested a whole line ago (behind the last line: unused)
+                    PROF_T0();
                     vm_wait<0>();
+                    PROF_ADD(2);
                     if (HALF && follows(i + 1 < my_lines ? i + 1 : my_lines - 1)) {
 #pragma unroll
                         for (int m = 0; m < NEWH; ++m) { cur[m] = cur[m + NEWH]; cur[m + NEWH] = land[64 * (m + NEWH) + lane]; }
@@ -594,7 +969,13 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #pragma unroll
                         for (int m = 0; m < TE; ++m) cur[m] = land[64 * m + lane];
                     }
+#ifndef SPEC_ABL_TEAM_NOWAIT
+                    PROF_T0();
+                    if (!slot_free) PROF_INC(5);
                     if (!slot_free && !team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
+                    PROF_ADD(3);
+#endif
+                    TRACE(4, i);
                     if (tid == 0) glds4_sc1(ring + 32 * ((i + 1) % a.ring) + 16, pland_addr + 128u * ((i + 1) & 1u));  // before the stores
                     cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
                     asm volatile("" ::: "memory");
@@ -603,11 +984,16 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     asm volatile("" ::: "memory");  // the loads below stay behind the stores above
                     pending = slot;
                     issue_next(i + 2);
+                    TRACE(5, i);
                     __syncthreads();  // this line's last LDS reads | the next line's first LDS writes
                 }
                 vm_wait<0>();
                 if (lane == 0 && atomicAdd(&s_arrive, 1u) + 1 == WAVES * my_lines)
                     __hip_atomic_fetch_add(ring + 32 * pending, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SPEC_TEAM_PROF
+                pf[0] = __builtin_readcyclecounter() - pf_begin;
+#endif
+                PROF_OUT(1);
                 return;
             }
         }
@@ -649,18 +1035,26 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                         v[m].y *= w;
                     }
                 }
+#ifndef SPEC_ABL_TEAM_NOFFT
                 dft8(v);
+#endif
                 xstore0<R>(v, t0, lds + (size_t)q0 * PA::SL);
                 __syncthreads();
                 xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);  // thread roles change here: a column's threads in one wave
                 wave_sync();
+#ifndef SPEC_ABL_TEAM_NOFFT
                 if constexpr (TWREG) twr.pass1(v);
                 else pass1<R, L1, WG>(v, t1, tab);
+#endif
                 xstore1<R>(v, t1, lds + (size_t)q1 * PA::SL);
                 wave_sync();
                 xload<R, L1, WG>(v, t1, lds + (size_t)q1 * PA::SL);
                 finish(v);
+#ifndef SPEC_ABL_TEAM_NOWAIT
                 if (!team_wait(ring + 32 * slot + 16, NT * round, sync, &s_flag)) return;
+#else
+                __syncthreads();
+#endif
                 cx<R> *dst = slots + (uint64_t)slot * N + (uint64_t)n2 * N1;
 #pragma unroll
                 for (int m = 0; m < TE; ++m) st_slot<R>(dst + t1 + m * PA::T, v[m]);
@@ -671,6 +1065,9 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         }
     } else {
         // ================= row side: tile of C rows k1, N2-point transforms over n2, epilogue ===============
+#ifdef SPEC_ABL_TEAM_NOB
+        return;
+#endif
         const uint32_t r0 = (member - NT) * PB::C;
         const int q0 = tid % PB::C, t0 = tid / PB::C;  // rows k1 fastest: the slot reads and the final stores
         cx<R> *tab = lds + (size_t)PB::C * PB::SL;
@@ -692,6 +1089,14 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             auto emit = [&](auto fmt_tag) {  // one format per call: the branch on the format is outside the bins
                 constexpr int FMT = decltype(fmt_tag)::value;
                 using TO = std::conditional_t<(FMT >= OUT_DB20_F64), double, float>;
+#if defined(SPEC_ABL_TEAM_NOSTORE)
+                between(std::integral_constant<int, 4>{});
+#pragma unroll
+                for (int m = 0; m < TE; ++m) {
+                    const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + m * PB::T);
+                    emit_bin<R, FMT>(a.out, base + ((k + N / 2) & (N - 1)), v[m], s_dbt);  // SS:78
+                }
+#else
                 TO *out = static_cast<TO *>(a.out);
                 // the epilogue in two halves: the first half's stores go out while the second half is computed (the
                 // ring poll in front of the first store: every store of the line stays younger than it); 1-2 % over
@@ -705,9 +1110,11 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     cx<R> z[HB];
 #pragma unroll
                     for (int m = 0; m < HB; ++m) z[m] = v[h * HB + m];
+#ifndef SPEC_ABL_TEAM_NOEPI
                     if constexpr (FMT == OUT_DB20_F64 && sizeof(R) == 8) {
                         db20_tab_n<HB>(z, s_dbt, d);
                     } else
+#endif
                     if constexpr (FMT == OUT_DB20_F32 && sizeof(R) == 4) {
                         // fp32 lines: ONE range test per thread and half (as the packed family's epilogue, spec_v2.h): while
                         // every |X|^2 is in [1e-4, 1e37), |X| + 1e-10 == |X| in fp32 and the value is 10 log10(p) -- one
@@ -731,6 +1138,16 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
 #pragma unroll
                         for (int m = 0; m < HB; ++m) d[m] = (TO)bin_value<R, FMT>(z[m], s_dbt);
                     }
+#ifdef SPEC_TEAM_SINGLE_STORES
+                    // one store per bin: a thread holds bin k1 = r0 + q0 of eight rows k2 (the C lanes of a row k2 write one run)
+                    asm volatile("" ::: "memory");
+                    if (h == 0) between(std::integral_constant<int, 4>{});
+#pragma unroll
+                    for (int m = 0; m < HB; ++m) {
+                        const uint32_t k = (r0 + q0) + (uint32_t)N1 * (t0 + (h * HB + m) * PB::T);
+                        __builtin_nontemporal_store(d[m], out + base + ((k + N / 2) & (N - 1)));  // SS:78
+                    }
+#else
                     // A thread holds bin k1 = r0 + q0 of eight rows k2; its neighbour (lane ^ 1) holds k1 ^ 1 of the same
                     // rows.  Even lanes store {k1, k1 + 1} of the rows m = 0, 2, 4, 6, odd lanes {k1 - 1, k1} of the rows
                     // m = 1, 3, 5, 7: TE / 2 stores of two bins each instead of TE stores of one.
@@ -746,7 +1163,9 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                         const uint32_t k = (r0 + ((uint32_t)q0 & ~1u)) + (uint32_t)N1 * k2;  // the even bin of the pair
                         st_pair<TO>(out + base + ((k + N / 2) & (N - 1)), odd ? o[mo] : d[me], odd ? d[mo] : o[me]);  // SS:78
                     }
+#endif
                 }
+#endif
             };
             asm volatile("" ::: "memory");
             emit(std::integral_constant<int, OUTFMT>{});
@@ -760,20 +1179,30 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
         // Plain form: both exchanges in the line buffers, four barriers per line, stages 0 .. 3.
         auto rest_of_line = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
             between(std::integral_constant<int, 0>{});
+            PROF_PH(2);  // hand-back, first requests for the next tile
             xload<R, L2, WG>(v, t0, line_lds);
             __syncthreads();
+            PROF_PH(3);
             between(std::integral_constant<int, 1>{});
+#ifndef SPEC_ABL_TEAM_NOFFT
             if constexpr (TWREG) twr.pass1(v);
             else pass1<R, L2, WG>(v, t0, tab);
+#endif
             between(std::integral_constant<int, 2>{});
             xstore1<R>(v, t0, line_lds);
             __syncthreads();
+            PROF_PH(4);
             between(std::integral_constant<int, 3>{});
             xload<R, L2, WG>(v, t0, line_lds);
+#ifndef SPEC_ABL_TEAM_NOFFT
             if constexpr (TWREG) twr.pass2(v);
             else pass2<R, L2, WG>(v, t0, tab);
+#endif
+            PROF_PH(5);
             epilogue(v, line, between);
+            PROF_PH(6);
             __syncthreads();  // the line buffers are rewritten by the next line's first exchange
+            PROF_PH(7);
         };
         // Pipelined form: the FIRST exchange lives in the landing strips.  After pass 0 the threads of wave w hold,
         // of every row q of the tile, the G = 512 / C consecutive elements [w G, (w + 1) G): C rows x G elements =
@@ -799,18 +1228,27 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             for (int m = 0; m < TE; ++m) v[m] = sx_rd[(m / (int)SXR) * (TE * 64) + (int)PB::T * (m % (int)SXR)];
         };
         auto rest_of_line_sx = [&](cx<R> (&v)[TE], uint32_t line, auto between) {
+            PROF_PH(2);
             xload0s(v);
+            PROF_PH(3);
+#ifndef SPEC_ABL_TEAM_NOFFT
             if constexpr (TWREG) twr.pass1(v);
             else pass1<R, L2, WG>(v, t0, tab);
+#endif
             xstore1<R>(v, t0, line_lds);
             __syncthreads();  // everybody has read the strips and written the line buffers
+            PROF_PH(4);
             between(std::integral_constant<int, 3>{});
             xload<R, L2, WG>(v, t0, line_lds);
             between(std::integral_constant<int, 5>{});
+#ifndef SPEC_ABL_TEAM_NOFFT
             if constexpr (TWREG) twr.pass2(v);
             else pass2<R, L2, WG>(v, t0, tab);
+#endif
             between(std::integral_constant<int, 6>{});
+            PROF_PH(5);
             epilogue(v, line, between);
+            PROF_PH(6);
         };
         (void)xstore0s; (void)rest_of_line_sx; (void)rest_of_line;
         auto ready = [&](uint32_t j, uint32_t w) { return j < my_lines && (int32_t)(w - NT * APT * (j / a.ring + 1)) >= 0; };
@@ -831,23 +1269,50 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
             auto issue_poll = [&](uint32_t j) {  // doneA of line j's slot (lane 0)
                 if (tid == 0 && j < my_lines) glds4_sc1(ring + 32 * (j % a.ring), pland_addr);
             };
+#ifndef SPEC_ABL_TEAM_NOWAIT
             if (!team_wait(ring, NT * APT, sync, &s_flag)) return;
+#endif
             issue(0);
             issue_poll(1);
             vm_wait<0>();  // the first tile: nothing to overlap with yet
+            PROF_DECL;
+#ifdef SPEC_TEAM_PROF
+            const unsigned long long pf_begin = __builtin_readcyclecounter();
+#endif
             for (uint32_t i = 0; i < my_lines; ++i) {
                 const uint32_t slot = i % a.ring;
+#ifdef SPEC_TEAM_PROF
+                ph_t = __builtin_readcyclecounter();
+#endif
+                TRACE(0, i);
+                PROF_T0();
                 vm_wait<TEAM_NST>();  // tile i and the poll have landed; the stores of line i - 1 fly on
+                PROF_ADD(1);
+                TRACE(1, i);
                 cx<R> v[TE];
 #pragma unroll
                 for (int m = 0; m < TE; ++m) v[m] = land[64 * m + lane];
+#ifndef SPEC_ABL_TEAM_NOFFT
                 dft8(v);
+#endif
+#ifdef SPEC_TEAM_NO_STRIPX
+                xstore0<R>(v, t0, line_lds);
+#else
                 xstore0s(v);  // into this wave's own strip (just read): no barrier in front
+#endif
                 if (tid == 0) s_next = ready(i + 1, pland[0]);
+                PROF_PH(0);
                 __syncthreads();
+                PROF_PH(1);
                 // every thread has consumed its slot reads: hand the slot back before the rest of the transform
                 if (tid == 0) __hip_atomic_fetch_add(ring + 32 * slot + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SPEC_ABL_TEAM_NOWAIT
+                const bool ahead = i + 1 < my_lines;
+#else
                 const bool ahead = s_next != 0;
+#endif
+                TRACE(2, i);
+                if (ahead) { TRACE(7, i); }
                 auto requests = [&](auto stage) {  // every request is older than the line's output stores
                     constexpr int ST = decltype(stage)::value, Q = TE / 4;
                     if constexpr (ST == 4) {
@@ -855,22 +1320,44 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                         // top of the next line, and a "not yet" costs that line a blocking wait and an exposed tile read
                         issue_poll(i + 2);
                     } else if constexpr (ST < 4) {
+#ifdef SPEC_TEAM_NO_STRIPX
+                        if (ahead) issue_part(i + 1, std::integral_constant<int, ST * Q>{}, std::integral_constant<int, ST * Q + Q>{});
+#else
                         // strip exchange: nothing may land before everybody has read the strips (stage 3 is the first one
                         // behind that barrier): half of the tile there, a quarter each behind the next two stretches
                         if constexpr (ST == 3) { if (ahead) issue_part(i + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * Q>{}); }
+#endif
                     } else if constexpr (ST == 5) {
                         if (ahead) issue_part(i + 1, std::integral_constant<int, 2 * Q>{}, std::integral_constant<int, 3 * Q>{});
                     } else if constexpr (ST == 6) {
                         if (ahead) issue_part(i + 1, std::integral_constant<int, 3 * Q>{}, std::integral_constant<int, 4 * Q>{});
                     }
                 };
+#ifdef SPEC_TEAM_NO_STRIPX
+                rest_of_line(v, line_of(i), requests);
+#else
                 rest_of_line_sx(v, line_of(i), requests);
+#endif
+                TRACE(4, i);
                 if (!ahead && i + 1 < my_lines) {  // the column side is not ahead: wait for it here
+                    PROF_T0();
+                    PROF_INC(5);
+#ifndef SPEC_ABL_TEAM_NOWAIT
                     if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * APT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
+#endif
+                    PROF_ADD(3);
+                    TRACE(5, i);
+                    PROF_T0();
                     issue(i + 1);
                     vm_wait<0>();  // nothing younger to leave in flight on this path
+                    PROF_ADD(2);
+                    TRACE(6, i);
                 }
             }
+#ifdef SPEC_TEAM_PROF
+            pf[0] = __builtin_readcyclecounter() - pf_begin;
+#endif
+            PROF_OUT(2);
         } else {
             // ---- plain form (fp32): the next tile requested as soon as the column side has it, loads the compiler knows
             auto load_tile = [&](uint32_t i, cx<R> (&x)[TE]) {
@@ -881,14 +1368,18 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                     x[m] = ld_slot<R>(rs, (int)(((uint32_t)(t0 + m * PB::T) * N1 + r0 + q0) * sizeof(cx<R>)));
             };
             cx<R> nxt[TE];
+#ifndef SPEC_ABL_TEAM_NOWAIT
             if (!team_wait(ring, NT * APT, sync, &s_flag)) return;
+#endif
             load_tile(0, nxt);
             for (uint32_t i = 0; i < my_lines; ++i) {
                 const uint32_t slot = i % a.ring;
                 cx<R> v[TE];
 #pragma unroll
                 for (int m = 0; m < TE; ++m) v[m] = nxt[m];
+#ifndef SPEC_ABL_TEAM_NOFFT
                 dft8(v);
+#endif
                 xstore0<R>(v, t0, line_lds);
                 if (tid == 0) s_next = ready(i + 1, ld_sc1(ring + 32 * ((i + 1) % a.ring)));
                 __syncthreads();
@@ -897,7 +1388,9 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 2) void large_team_kernel(const Tea
                 if (ahead) load_tile(i + 1, nxt);
                 rest_of_line(v, line_of(i), [](auto) {});
                 if (!ahead && i + 1 < my_lines) {
+#ifndef SPEC_ABL_TEAM_NOWAIT
                     if (!team_wait(ring + 32 * ((i + 1) % a.ring), NT * APT * ((i + 1) / a.ring + 1), sync, &s_flag)) return;
+#endif
                     load_tile(i + 1, nxt);
                 }
             }
@@ -960,7 +1453,11 @@ hipError_t launch_team(const TeamArgs &a, int wg, int n_cu, uint32_t *teams_max,
 
 }  // namespace
 
+#ifdef SPEC_TEAM_PROF
+size_t large_team_sync_bytes() { return (size_t)TEAM_SYNC_WORDS * sizeof(uint32_t) + 1024 * 128 + 64 * 32 * 8 * 8; }  // + 16 words x 1024 workgroups + the event trace
+#else
 size_t large_team_sync_bytes() { return (size_t)TEAM_SYNC_WORDS * sizeof(uint32_t); }
+#endif
 uint32_t large_team_prof_offset_bytes() { return TEAM_SYNC_WORDS * (uint32_t)sizeof(uint32_t); }
 uint32_t large_team_abort_word() { return TS_ABORT; }
 
