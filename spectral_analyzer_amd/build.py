@@ -130,14 +130,14 @@ def _compile(src: str, objdir: str, extra) -> str:
     if not os.path.exists(asm):
         raise RuntimeError("no device assembly for %s (expected %s): the ISA lint cannot run" % (src, asm))
     bad = store_hazard_findings(asm)
+    spills = kernel_spills(asm)
     for f in os.listdir(objdir):  # the other temporaries (bitcode, preprocessed source: hundreds of MB over all units)
         if f.startswith(stem + "-") or f.startswith(stem + ".hip-"):
-            if not f.endswith(".s") or "host" in f:
-                os.remove(os.path.join(objdir, f))
+            os.remove(os.path.join(objdir, f))   # (the device assembly too, once linted below: 120 MB over all units)
     if bad:
         raise RuntimeError("ISA lint (store-data hazard, build.py store_hazard_findings) on %s:\n%s" % (src, "\n".join(bad[:20])))
     with open(os.path.splitext(obj)[0] + ".spills", "w") as f:  # which kernels of this unit spill (tests/test_abi.py reads the product's)
-        for k, n in sorted(kernel_spills(asm).items()):
+        for k, n in sorted(spills.items()):
             f.write("%s %d\n" % (k, n))
     return obj
 

@@ -25,6 +25,7 @@
 
 #include "spec_fft.h"
 #include "spec_internal.h"
+#include "spec_dispatch_table.h"
 
 using namespace specgpu;
 
@@ -590,30 +591,14 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
     if (st != SPEC_OK) return st;
     a.win_hann = window == SPEC_WIN_HANN;
     const uint64_t out_esz = fmt >= SPEC_OUT_DB20_F64 ? 8 : 4, nfft = 1ull << log2n;
-    // 16384-point lines the same way (256-thread workgroups, two per CU) where that is faster than the family's kernel --
-    // measured case by case (tools/bench_mid.py, profiles/r04_mid.txt; re-measured after the family's 32-point threads got their
-    // Hann window from LDS, which turned every windowed case but two its way).  "mid_single" = 2 (default) that rule, 1 always, 0 never:
-    //   big-endian cf32 / ci16: half-line below hop = N (the family has one variant without register reuse: 0.32-0.42 vs 0.36-0.46)
-    //   with a window: the family (the half-line kernel's computed window has its cosine in fp64 since the accuracy runs of round 4: 0.47 vs 0.50)
-    //   without: cf32 half-line at hops other than N/4, N/2 (the family keeps the overlap in registers there: 0.43 / 0.52 vs 0.37 / 0.48);
-    //            ci16 half-line except at N/4; cu8 / ci8 half-line (+1 ... 2 points)
+    // 8192- and 16384-point lines have two kernels: the family's (spec_v2.h) and the half-line kernel of spec_k_v2h.hip (smaller
+    // workgroups, two or three per CU).  Which one is faster is MEASURED cell by cell -- format x byte order x hop class x window --
+    // by tools/tune_dispatch.py, which generates spec_dispatch_table.h; "mid_single" (16384) / "small_single" (8192) = 2 (default)
+    // follow the table, 1 always takes the half-line kernel, 0 never.  (Rounds 3-4 transcribed the rule by hand from such tables.)
     bool mid_single = false;
-    if (log2n == 14 && !f64 && !d_sel && !c->opt_force_generic && c->opt_mid_single) {
-        const bool reuse_hop = hop == nfft / 4 || hop == nfft / 2;
-        bool half;
-        if (a.be && (a.kind == K_CF32 || a.kind == K_CI16)) half = hop != nfft;
-        else if (window != SPEC_WIN_RECT) half = false;
-        else if (a.kind == K_CF32) half = !reuse_hop;
-        else if (a.kind == K_CI16) half = hop != nfft / 4;
-        else half = true;
-        mid_single = c->opt_mid_single == 1 || half;
-    }
-    // 8192-point lines ("small_single", tools/bench_mid.py 8192, profiles/r04_small.txt): level with the family's kernel (+-2 points)
-    // except for cf32 where the family has no register-reuse variant -- big-endian files, and hops other than N/4, N/2, N --
-    // there 8 ... 11 points of the roofline faster (0.47 -> 0.56, 0.55 -> 0.66); not at hop = N (0.70 either way)
-    if (log2n == 13 && !f64 && !d_sel && !c->opt_force_generic && c->opt_small_single) {
-        const bool wins = a.kind == K_CF32 && hop != nfft && (a.be || (hop != nfft / 2 && hop != nfft / 4));
-        mid_single = c->opt_small_single == 1 || wins;
+    if ((log2n == 14 || log2n == 13) && !f64 && !d_sel && !c->opt_force_generic) {
+        const int64_t knob = log2n == 14 ? c->opt_mid_single : c->opt_small_single;
+        mid_single = knob == 1 || (knob == 2 && dispatch_half_line(log2n, a.kind, a.be != 0, hop, window != SPEC_WIN_RECT));
     }
     if (((large && c->opt_large_single && c->opt_large_team == 1) || mid_single) && !f64 && !d_sel &&
         v2h_applicable(log2n, a.kind, a.out_fmt, n_lines, hop)) {

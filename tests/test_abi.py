@@ -177,3 +177,33 @@ def test_headline_kernels_do_not_spill():
         assert hits, "no kernel matches %r" % pat
         for k, v in hits.items():
             assert v <= allowed, "%s spills %d vector registers (allowed %d)" % (k, v, allowed)
+
+
+def test_dispatch_table_is_generated_and_complete():
+    """The 8192- / 16384-point choice between the family's kernel and the half-line kernel is a GENERATED table
+    (tools/tune_dispatch.py -> csrc/spec_dispatch_table.h): every cell of size x format x hop class x
+    window is there, carries the fractions it was decided from, both verdicts occur at both sizes (so "mid_single" /
+    "small_single" = 2 really exercises both kernels; tests/test_gpu_v2h.py checks 0 / 1 / 2 on the GPU), and the C ABI reads it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import tune_dispatch as td
+    cells = td.parse_header()
+    assert len(cells) == 2 * 6 * 4 * 2
+    for n in td.SIZES:
+        vals = {v for (size, *_), v in cells.items() if size == n}
+        assert vals == {0, 1}, "size %d: the table never takes one of the two kernels" % n
+    text = open(td.HEADER).read()
+    assert "GENERATED by tools/tune_dispatch.py" in text and len(re.findall(r"rect [\d.]+ / [\d.]+\s+Hann [\d.]+ / [\d.]+", text)) == 48
+    # emit(parse) round trip: the committed header is what the generator writes for the fractions in its own comments
+    frac = {}
+    rows = re.findall(r"rect ([\d.]+) / ([\d.]+)\s+Hann ([\d.]+) / ([\d.]+)", text)
+    it = iter(rows)
+    for n in td.SIZES:
+        for f in td.FORMATS:
+            for h in td.HOPS:
+                r = next(it)
+                frac[(n, f, h, 0)], frac[(n, f, h, 1)] = (float(r[0]), float(r[1])), (float(r[2]), float(r[3]))
+    regenerated = td.emit(frac, "x")
+    assert regenerated.split("#pragma once")[1] == text.split("#pragma once")[1]
+    capi = open(os.path.join(ROOT, "spectral_analyzer_amd", "csrc", "spec_capi.hip")).read()
+    assert "dispatch_half_line(" in capi and '#include "spec_dispatch_table.h"' in capi
