@@ -3,7 +3,7 @@
 # the two workloads whose kernels changed this round.  Outputs under gpurun_out/; tools/summarize_profile.py turns
 # the profile directories into profiles/<round>_*.
 #   usage: tools/run_round_bench.sh <round-tag>
-R=${1:-r03}
+R=${1:-r05}
 mkdir -p gpurun_out
 for w in cfg2 cfg3 cfg1; do
   timeout -k 10 400 python bench.py --workload $w > gpurun_out/${R}_bench_$w.json 2> gpurun_out/${R}_bench_$w.err || echo "bench $w failed"

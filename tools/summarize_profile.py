@@ -16,7 +16,7 @@ os.makedirs(dst, exist_ok=True)
 stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, rnd + "_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-main = max(rows, key=lambda r: float(r["TotalDurationNs"]) if "synth" not in r["Name"] else 0)
+main = max(rows, key=lambda r: float(r["TotalDurationNs"]) if not any(x in r["Name"] for x in ("synth", "copyBuffer", "fill")) else 0)
 # timed launches only: the last `steps` dispatches of the dominant kernel in the trace
 trace = glob.glob(os.path.join(src, "stats", "*", "*_kernel_trace.csv"))[0]
 durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace))
@@ -73,6 +73,11 @@ with open(os.path.join(dst, rnd + "_summary.md"), "w") as f:
     f.write("\nPMC means per launch of the dominant kernel:\n\n")
     for k in sorted(pmc):
         f.write("* %s = %.4g\n" % (k, pmc[k]))
+    if pmc.get("GRBM_GUI_ACTIVE") and timed_avg_ns:
+        # the shader clock the counter pass ran at (GRBM cycles / kernel time of the stats pass; the two
+        # passes are separate processes on the same box, so this is approximate -- bench.py's roofline.clocks is the direct reading)
+        f.write("\nGRBM_GUI_ACTIVE / kernel time = %.0f MHz (shader clock during the counter pass, approximate)\n"
+                % (pmc["GRBM_GUI_ACTIVE"] / (timed_avg_ns * 1e-9) / 1e6))
     f.write("\nHBM traffic per launch: read %.3f GB (FETCH_SIZE KiB x 1024 x 2, gfx950 correction) + write %.3f GB "
             "= %.3f GB\n" % (fetch / 1e9, write / 1e9, traffic / 1e9))
     if os.path.exists(bj):
