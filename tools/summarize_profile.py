@@ -77,7 +77,7 @@ with open(os.path.join(dst, rnd + "_summary.md"), "w") as f:
         # the shader clock the counter pass ran at (GRBM cycles / kernel time of the stats pass; the two
         # passes are separate processes on the same box, so this is approximate -- bench.py's roofline.clocks is the direct reading)
         f.write("\nGRBM_GUI_ACTIVE / kernel time = %.0f MHz (shader clock during the counter pass, approximate)\n"
-                % (pmc["GRBM_GUI_ACTIVE"] / (timed_avg_ns * 1e-9) / 1e6))
+                % (pmc["GRBM_GUI_ACTIVE"] / 8 / (timed_avg_ns * 1e-9) / 1e6))   # (the counter is summed over the 8 XCDs)
     f.write("\nHBM traffic per launch: read %.3f GB (FETCH_SIZE KiB x 1024 x 2, gfx950 correction) + write %.3f GB "
             "= %.3f GB\n" % (fetch / 1e9, write / 1e9, traffic / 1e9))
     if os.path.exists(bj):
