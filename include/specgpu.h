@@ -169,11 +169,12 @@ void *spec_stream(const spec_ctx *ctx);
  *   "small_single" = 2 | 1 | 0   8192-point fp32 lines through it (16 points per thread and half, three workgroups per CU):
  *                     2 (default) = cf32 where the family's kernel has no register-reuse variant (big-endian files, hops other
  *                     than N/4, N/2, N; 8 ... 11 points of the roofline faster; level everywhere else), 1 = always, 0 = never
- *   "large_pair" = 1 | 0   65536-point fp32 lines (the default dispatch, "large_team" = 1): 1 (default) = a PAIR of workgroups
+ *   "large_pair" = 1 | 0 | 2   65536-point fp32 lines (the default dispatch, "large_team" = 1): 1 (default) = a PAIR of workgroups
  *                     per line, each a single-workgroup kernel on two of the four outputs of a radix-4 step taken in registers
  *                     (two 16384-point transforms each; nothing is handed over, nothing waits): 1.04x ... 5.3x the four-step
  *                     team kernel in all 30 measured format / hop / window cases (cf32 0.25 -> 0.31 of 8 TB/s, ci16 0.09 -> 0.34);
- *                     0 = the four-step paths of "large_team"
+ *                     0 = the four-step paths of "large_team".  32768-point fp64 lines have the fp64 twin of that kernel: 1 = where
+ *                     it was measured faster than the team kernel (every format but little-endian cf64: 1.2x ... 1.8x), 2 = always
  *   "pair_interleave" = 1 | 0   line order of that kernel: 1 (default) = the sixteen pairs of an XCD walk one block of lines
  *                     together (pair s takes lines s, s + 16, ...: what a line shares with its neighbour is in that XCD's L2),
  *                     0 = consecutive lines per pair

@@ -388,7 +388,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "large_block")) c->opt_large_block = value < 0 ? 0 : (value > 65536 ? 65536 : value);
     else if (!strcmp(key, "large_team_fake_abort")) c->opt_team_fake_abort = value != 0;
     else if (!strcmp(key, "large_single")) c->opt_large_single = value != 0;
-    else if (!strcmp(key, "large_pair")) c->opt_large_pair = value != 0;
+    else if (!strcmp(key, "large_pair")) c->opt_large_pair = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "pair_interleave")) c->opt_pair_interleave = value != 0;
     else if (!strcmp(key, "mid_single")) c->opt_mid_single = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "small_single")) c->opt_small_single = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -651,6 +651,31 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
             hipError_t e = launch_v2q_spectro(a, tw_q, tw_full64, (uint32_t)run, (int)c->opt_pair_interleave, c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "65536-point launch: %s", hipGetErrorString(e));
+            done += a.n_lines;
+        }
+        return SPEC_OK;
+    }
+    // 32768-point fp64 lines: the fp64 twin of the paired kernel above (spec_k_v3h.hip v3q_kernel: two 8192-point fp64 transforms per
+    // workgroup).  Measured against the team kernel (tools/bench_v3q.py, profiles/r05_v3q.txt): 1.2x ... 1.8x faster for every format
+    // but little-endian cf64 -- the team kernel's best case (0.30 of 8 TB/s against 0.22: the pair kernel's cf64 variants spill ~80
+    // registers) -- which "large_pair" = 1 (default) therefore leaves where it was; 2 = always the pair.
+    if (large && f64 && c->opt_large_team == 1 && !d_sel && v3q_applicable(log2n, a.kind, n_lines, hop) &&
+        (c->opt_large_pair == 2 || (c->opt_large_pair == 1 && !(a.kind == K_CF64 && !a.be)))) {
+        const void *tw_q = nullptr;
+        if ((st = get_twiddles(c, log2n - 2, true, &tw_q)) != SPEC_OK) return st;
+        uint64_t done = 0;
+        while (done < n_lines) {
+            const uint64_t rem = n_lines - done;
+            uint64_t run = c->opt_lines_per_wg > 0 ? (uint64_t)c->opt_lines_per_wg : (rem + (uint64_t)c->n_cu - 1) / (uint64_t)c->n_cu;
+            if (run < 1) run = 1;
+            if (run > 32) run = 32;
+            const uint64_t ilv = c->opt_pair_interleave ? 16 : 1;
+            while (run > 1 && run * ilv * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;  // 32-bit offsets in a span
+            a.n_lines = rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull;
+            a.iq = d_first + done * (uint64_t)hop * a.bps;
+            a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            hipError_t e = launch_v3q_spectro(a, tw_q, (uint32_t)run, (int)c->opt_pair_interleave, c->stream);
+            if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "32768-point fp64 launch: %s", hipGetErrorString(e));
             done += a.n_lines;
         }
         return SPEC_OK;

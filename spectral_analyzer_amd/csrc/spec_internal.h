@@ -98,6 +98,9 @@ bool v2q_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t
 hipError_t launch_v2q_spectro(const WfArgs &w, const void *tw_q, const void *tw_full64, uint32_t run, int interleave, hipStream_t s);
 // 16384-point fp64 lines in one workgroup (spec_k_v3h.hip): w.tw = v2d W_16384 table, tw_half = v2d W_8192 table
 bool v3h_applicable(int log2n, int kind, uint64_t n_lines, uint32_t hop);
+// 32768-point fp64 lines by PAIRS of workgroups (spec_k_v3h.hip, v3q_kernel): w.tw = v2d W_32768 table, tw_q = v2d W_8192 table
+bool v3q_applicable(int log2n, int kind, uint64_t n_lines, uint32_t hop);
+hipError_t launch_v3q_spectro(const WfArgs &w, const void *tw_q, uint32_t run, int interleave, hipStream_t s);
 hipError_t launch_v3h_spectro(const WfArgs &w, const void *tw_half, uint32_t run, hipStream_t s);
 bool v2_sel_applicable(int log2n, int kind, int be, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v2_spectro_sel(const WfArgs &w, int log2n, uint32_t run, const int32_t *sel, uint32_t out_stride,
