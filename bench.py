@@ -130,6 +130,58 @@ class ClockSampler:
         return out
 
 
+def live_traffic(args):
+    """HBM-side bytes per launch of THIS workload on THIS box, measured now: two short rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+    the guide's gfx950 corrections) of this same script as CHILD processes, started before this process has made any HIP call
+    (roofline.traffic used to be a constant stamped from an earlier profile).  Returns (bytes, note) or
+    (None, reason); never raises.  Skipped under a profiler, under torchrun, inside the children themselves and with
+    --no-live-traffic (the stamped figure of profiles/pmc_traffic.json is then reported, and says so)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if os.environ.get("SPEC_BENCH_CHILD") or "RANK" in os.environ or args.gpus != 1:
+        return None, "not measured in this process"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "running under a profiler"
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    me = os.path.abspath(__file__)
+    base = [sys.executable, me, "--workload", args.workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    if args.log2_samples is not None:
+        base += ["--log2-samples", str(args.log2_samples)]
+    if args.n_psd is not None:
+        base += ["--n-psd", str(args.n_psd)]
+    for o in args.opt:
+        base += ["--opt", o]
+    env = dict(os.environ, SPEC_BENCH_CHILD="1", TMPDIR="/tmp")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="spec_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", *base], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                k = row["Kernel_Name"]
+                if row["Counter_Name"] == counter and not any(x in k for x in ("synth", "copyBuffer", "fill")):
+                    per.setdefault(k, []).append(float(row["Counter_Value"]))
+            if not per:
+                return None, "no kernel in the %s pass" % counter
+            if counter == "FETCH_SIZE":
+                out["kernel"] = max(per, key=lambda k: sum(per[k]))       # the dominant kernel: the one that reads most
+            v = per.get(out["kernel"]) or max(per.values(), key=sum)
+            out[counter] = sum(v) / len(v)
+        # MI355X_MICROARCH.md, HBM: both counters in KiB; FETCH_SIZE reads exactly half of a wide coalesced stream on gfx950 -> x2
+        return out["FETCH_SIZE"] * 1024 * 2 + out["WRITE_SIZE"] * 1024, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (3 launches each), kernel " + out["kernel"].replace("(anonymous namespace)::", "").replace("specgpu::", "").split("(")[0][:80]
+    except Exception as e:  # noqa: BLE001
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def usable_cores() -> int:
     """CPU threads this process may actually run on: affinity mask, capped by a cgroup quota."""
     n = len(os.sched_getaffinity(0))
@@ -191,6 +243,7 @@ def main() -> None:
     ap.add_argument("--log2-samples", type=int, default=None, help="override samples per GPU (debug)")
     ap.add_argument("--n-psd", type=int, default=None, help="cfg4: PSDs per GPU and step (default 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="report the stamped traffic figure instead of measuring it (two rocprofv3 child runs)")
     ap.add_argument("--gather-steps", type=int, default=3, help="N > 1: steps of the compute+gather timing")
     ap.add_argument("--gather-chunks", type=int, default=8)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
@@ -206,6 +259,8 @@ def main() -> None:
         args.gpus = world
     if args.workload is None:
         args.workload = "cfg2"
+    # BEFORE anything touches the GPU: the counter passes run as children of this process
+    live_bytes, live_note = (None, "--no-live-traffic") if args.no_live_traffic else live_traffic(args)
     # SPEC_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a ONE-GPU box -- every rank on device 0,
     # gloo instead of RCCL (which refuses two ranks on one device).  Never used by the driver.
     rehearse = os.environ.get("SPEC_BENCH_REHEARSE") == "1"
@@ -383,6 +438,10 @@ def main() -> None:
                     traffic = ent
             except Exception:
                 traffic = None
+        if live_bytes is not None:
+            traffic, traffic_stamp = live_bytes, {"measured": "live", "how": live_note}
+        elif traffic_stamp is not None:
+            traffic_stamp = dict(traffic_stamp, measured="stamped", live_skipped=live_note)
         if welch:
             # B_psd = S bps_in + 4 N; 5 N log2 N flops per segment.  35 flop per byte: the vector
             # ALUs bound this kernel, not HBM -- the roofline is the fp32 vector peak, the HBM figure rides along

@@ -227,11 +227,7 @@ __device__ __forceinline__ void v2q_body(const V2qArgs &a, uint32_t line0, uint3
             if constexpr (HAS_WIN) {
                 // Hann: w[n] = 1/2 - 1/2 cos(2 pi n / N); W_N^n = W_N^t W_128^m = (cos, -sin) in fp64 (spec_k_v2h.hip: formed from
                 // fp32 twiddles the cosine's error reached the tolerance); the four quarters see cos, -sin, -cos, sin
-#ifdef V2Q_WTAB_VOLATILE
-                const v2d cs = *(const volatile __attribute__((address_space(3))) v2d *)(wtab + m);
-#else
                 const v2d cs = wtab[m];  // one broadcast LDS read
-#endif
                 const double c = __builtin_fma(wt64.x, cs.x, -(wt64.y * cs.y)), ms = __builtin_fma(wt64.x, cs.y, wt64.y * cs.x);
                 const float w0 = (float)__builtin_fma(-0.5, c, 0.5), w2 = (float)__builtin_fma(0.5, c, 0.5);
                 const float w1 = (float)__builtin_fma(-0.5, ms, 0.5), w3 = (float)__builtin_fma(0.5, ms, 0.5);

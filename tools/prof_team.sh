@@ -8,10 +8,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/bench_under_prof.json 2> $OUT/stats.err || { tail -5 $OUT/stats.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --no-cpu-baseline --no-live-traffic "$@" > $OUT/bench_under_prof.json 2> $OUT/stats.err || { tail -5 $OUT/stats.err; exit 1; }
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
   name=$(echo $grp | tr ' ' '+' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /dev/null 2> $OUT/pmc_$name.err || tail -3 $OUT/pmc_$name.err
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic "$@" > /dev/null 2> $OUT/pmc_$name.err || tail -3 $OUT/pmc_$name.err
 done
 python3 - <<PY
 import csv, glob, collections

@@ -11,7 +11,7 @@ for w in $WLS; do
     if [ $v = product ]; then unset SPEC_LIB_VARIANT; else export SPEC_LIB_VARIANT=$v; fi
     for opt in ${OPTS:-none}; do
       o=""; [ $opt != none ] && o="--opt $opt"
-      echo "$w $v $opt: $(timeout -k 10 300 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline $o 2>/dev/null | line)" | tee -a $O
+      echo "$w $v $opt: $(timeout -k 10 300 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-live-traffic $o 2>/dev/null | line)" | tee -a $O
     done
   done
 done
