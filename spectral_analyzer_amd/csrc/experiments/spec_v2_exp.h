@@ -25,6 +25,22 @@ template <> struct Plan2<214> {
     static constexpr int LINE = ROWS * ROW;
 };
 template <int L> constexpr bool p2_rows() { return L == 214; }
+
+// Plan id 314 (round 5, DESIGN.md 8 item 2 "priced, not built" -> built): 16384 points on 1024 threads x 16 points = FOUR waves per
+// SIMD at 128 registers, radix 4 x 16 x 16 x 16 (three exchanges instead of two).  The time line of the 512-thread kernels shows
+// `vector + LDS` adding up because two waves per SIMD have nothing to fill each other's waits with; four might.  What makes 128
+// registers possible at all: the last pass's fifteen twiddles W_N^(r t) are formed from two LDS tables (as spec_k_v3h.hip does
+// in fp64), W_N^(r (t mod 32)) W_N^(32 r (t div 32)), instead of living in 30 registers.  Welch sums only (MODE 1).
+template <> struct Plan2<314> {
+    static constexpr int E = 16, N = 16384, T = N / E, NPASS = 4;
+    static constexpr int radix[4] = {4, 16, 16, 16};
+    static constexpr int WG = T, LPW = 1;
+    static constexpr bool WAVE_LOCAL = false;
+    static constexpr int PADSH = 4;
+    static constexpr int LINE = N + (N >> PADSH);
+};
+template <int L> constexpr bool p2_lds_twl() { return L == 314; }
+constexpr int P2_LDS_TWL_ENTRIES = 2 * 15 * 32;  // table A: (r - 1) 32 + j -> W_N^(r j); table B: (r - 1) 32 + h -> W_N^(32 r h)
 // multiple of T in the bin index of register m at the end of a transform: the row plan's last butterfly leaves its
 // outputs in split order (pk_dft32_split: even bins in the lower sixteen registers, odd bins in the upper)
 template <int L> constexpr int p2_bin_reg(int m) { return p2_rows<L>() ? (m < 16 ? 2 * m : 2 * (m - 16) + 1) : m; }

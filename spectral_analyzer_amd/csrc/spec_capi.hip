@@ -373,7 +373,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     }
     else if (!strcmp(key, "welch_rows")) {
 #ifdef SPEC_V2_ROWS
-        c->opt_welch_rows = value != 0;
+        c->opt_welch_rows = value < 0 ? 0 : (value > 2 ? 2 : value);  // 1: 16 x (32 x 32); 2: 1024 threads x 16 points (four waves per SIMD)
 #else
         if (value != 0) return fail(c, SPEC_EUNSUPPORTED, "welch_rows is an experiment: build the variant library (python -m spectral_analyzer_amd.build --variant v2rows)");
 #endif

@@ -20,7 +20,7 @@ hipError_t launch_v2_welch(const WelchArgs &w, int log2n, uint32_t run, uint32_t
     a.iq = w.iq; a.unit_stride = w.psd_stride_bytes; a.n_units = w.n_psd; a.n_lines = w.n_seg; a.hop = w.hop;
     a.run = run; a.wgs_per_unit = wgs_per_unit; a.tw = w.tw; a.win = w.win; a.out = w.partial; a.out_fmt = 0; a.be = w.be; a.win_hann = w.win_hann;
     a.final_out = wgs_per_unit == 1 && v2_lpw(log2n) == 1 ? w.final_out : nullptr; a.norm = w.norm; a.db = w.db;
-    a.rows = w.rows && log2n == 14;
+    a.rows = log2n == 14 ? w.rows : 0;
 #ifdef SPEC_V2_STAMPS
     a.sel = static_cast<const int32_t *>(g_stamp_buf);
     a.out_stride = g_stamp_first;

@@ -68,6 +68,8 @@ template <> struct Plan2<113> {
 #include "experiments/spec_v2_exp.h"
 #else
 template <int L> constexpr bool p2_rows() { return false; }
+template <int L> constexpr bool p2_lds_twl() { return false; }  // last-pass twiddles from two LDS tables (experiment plan 314)
+constexpr int P2_LDS_TWL_ENTRIES = 0;
 template <int L> constexpr int p2_bin_reg(int m) { return m; }  // multiple of T in the bin index of register m after a transform
 #define V2_STAMP(sp, id) do { (void)(sp); } while (0)
 template <typename V> __device__ __forceinline__ void v2_fft_rows(V (&)[32], int, V *, const V *, V (&)[16], uint32_t *) {}
@@ -93,7 +95,7 @@ template <int L> constexpr int p2_tab_entries() {
     else return p2_tab_off_of<L>(Plan2<L>::NPASS - 1);
 }
 template <int L, int ELEM = 8> constexpr size_t p2_lds_bytes() {  // ELEM: bytes per complex value (8 fp32, 16 fp64)
-    return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * ELEM + (size_t)p2_tab_entries<L>() * ELEM;
+    return (size_t)Plan2<L>::LPW * Plan2<L>::LINE * ELEM + (size_t)(p2_tab_entries<L>() + (p2_lds_twl<L>() ? P2_LDS_TWL_ENTRIES : 0)) * ELEM;
 }
 
 // ---- raw sample formats (SS:40-59); SCALE is folded into the epilogue -------------
@@ -203,10 +205,21 @@ __device__ __forceinline__ void v2_pass(V (&v)[Plan2<L>::E], int t, const V *tab
         for (int r = 0; r < R; ++r) u[r] = v[s + r * S];
         if constexpr (PASS == PL::NPASS - 1) {
             static_assert(R == 16 && S <= 2, "last pass: radix-16 butterflies");
+            if constexpr (p2_lds_twl<L>()) {  // (experiment plan: the twiddles formed from two LDS tables behind the middle passes' tables, five at a time)
+                static_assert(S == 1, "one butterfly per thread");
+                const V *ta = tab + p2_tab_entries<L>() + (t & 31), *tb = ta - (t & 31) + 15 * 32 + ((t >> 5) & 31);
 #pragma unroll
-            for (int r = 1; r < R; ++r) {
-                u[r] = pk_cmul(u[r], twl[r]);
-                if (s == 1) u[r] = r == 8 ? pk_mul_mi(u[r]) : pk_cmul_const(u[r], kW32[r][0], kW32[r][1]);
+                for (int r0 = 1; r0 < 16; r0 += 5) {
+#pragma unroll
+                    for (int r = r0; r < r0 + 5; ++r) u[r] = pk_cmul(u[r], pk_cmul(ta[(r - 1) * 32], tb[(r - 1) * 32]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
+                    u[r] = pk_cmul(u[r], twl[r]);
+                    if (s == 1) u[r] = r == 8 ? pk_mul_mi(u[r]) : pk_cmul_const(u[r], kW32[r][0], kW32[r][1]);
+                }
             }
         }
         pk_dft<R>(u);
@@ -405,8 +418,16 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     // ---- one-time set-up: LDS twiddle tables of the middle passes, last-pass registers
     if constexpr (PL::NPASS > 2) fill_tables<L, 1>(tab, tw, tid);
     v2f twl[16];
+    if constexpr (p2_lds_twl<L>()) {
+        v2f *tt = tab + p2_tab_entries<L>();
+        for (int e = tid; e < 15 * 32; e += PL::WG) {
+            tt[e] = tw[((e / 32 + 1) * (e % 32)) & (N - 1)];
+            tt[15 * 32 + e] = tw[((e / 32 + 1) * (e % 32) * 32) & (N - 1)];
+        }
+    } else {
 #pragma unroll
-    for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+        for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    }
     // window values of this thread's samples: registers for 16-point threads, re-read from
     // the L2-resident table every line for 32-point threads (no room)
     constexpr bool WIN_REGS = HAS_WIN && E == 16;  // (cf32: 61.0 % with the window in registers and 8 spilled VGPRs, 59.3 % reloading it)
@@ -626,7 +647,7 @@ hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
 #ifdef SPEC_FORCE_OCC  // experiments only
     constexpr int WAVES_PER_SIMD = PL::E == 32 ? 2 : SPEC_FORCE_OCC;
 #else
-    constexpr int WAVES_PER_SIMD = PL::E == 32 ? 2 : NEED <= 120 ? 4 : NEED <= 152 ? 3 : 2;
+    constexpr int WAVES_PER_SIMD = PL::WG == 1024 ? 4 : PL::E == 32 ? 2 : NEED <= 120 ? 4 : NEED <= 152 ? 3 : 2;
 #endif
     auto kern = v2_kernel<L, KIND, SH, HAS_WIN, MODE, BE, WAVES_PER_SIMD>;
     if (lds > 64 * 1024) {
@@ -696,6 +717,7 @@ template <int MODE> hipError_t v2_launch_n(const V2Args &a, int log2n, int kind,
     case 14:
 #ifdef SPEC_V2_ROWS
         if constexpr (MODE == 1) {
+            if (a.rows == 2) return v2_launch_kind<314, MODE>(a, kind, s);  // 1024 threads x 16 points
             if (a.rows && (a.win_hann == 1 || a.win_hann == 2)) return v2_launch_kind<214, MODE>(a, kind, s);
         }
 #endif
