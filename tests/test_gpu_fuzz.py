@@ -17,7 +17,7 @@ DTYPES = ["cf32_le", "cf32_be", "ci16_le", "ci16_be", "cu8", "ci8", "cf64_le", "
 def _cases(seed, n):
     rng = np.random.default_rng(seed)
     for _ in range(n):
-        log2n = int(rng.choice([1, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]))
+        log2n = int(rng.choice([1, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]))
         nfft = 1 << log2n
         hop = int(rng.choice([nfft, nfft // 2 or 1, nfft // 4 or 1, int(rng.integers(1, 3 * nfft + 1)), 9 * nfft]))
         dt = str(rng.choice(DTYPES))
