@@ -230,6 +230,10 @@ VARIANTS = _unique([
     ("v2qm12", (["-DV2Q_ST_AUX=2", "-DV2Q_M0=1", "-DV2Q_M1=8", "-DV2Q_M2=12"], ["spec_k_v2q.hip"])),
     ("v2qm22", (["-DV2Q_ST_AUX=2", "-DV2Q_M0=2", "-DV2Q_M1=12", "-DV2Q_M2=22"], ["spec_k_v2q.hip"])),
     ("v2qlnt", (["-DV2Q_LD_AUX=2"], ["spec_k_v2q.hip"])),
+    # the compiler's own scheduling strategies on the packed family (round 5; -mllvm options of this toolchain)
+    ("schilp", (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip"])),
+    ("schb0", (["-mllvm", "-amdgpu-schedule-metric-bias=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip"])),
+    ("schtrk", (["-mllvm", "-amdgpu-use-amdgpu-trackers"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip"])),
     # development aid: per-wave shader-clock stamps at the phase boundaries of the Welch kernels (tools/v2_timeline.py)
     ("v2stamp", (["-DSPEC_V2_STAMPS", "-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
     ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),
