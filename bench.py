@@ -55,6 +55,8 @@ WORKLOADS = {
     "n65536f": dict(kind="spectro", datatype="cf32_le", nfft=65536, hop=32768, log2s=30, window=0, out="f32"),
     "n32768f": dict(kind="spectro", datatype="cf32_le", nfft=32768, hop=16384, log2s=30, window=0, out="f32"),
     "n16384d": dict(kind="spectro", datatype="cf64_le", nfft=16384, hop=8192, log2s=30, window=0, out="f64"),
+    "n64": dict(kind="spectro", datatype="cf32_le", nfft=64, hop=32, log2s=28, window=0, out="f32"),
+    "n128": dict(kind="spectro", datatype="cf32_le", nfft=128, hop=64, log2s=28, window=0, out="f32"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 GATHER_TIMEOUT_S = 240  # N > 1: the compute + gather phase is abandoned after this long (the headline is kept)

@@ -25,12 +25,16 @@ struct V2nArgs {
     const uint8_t *iq;   // first byte of line 0
     uint32_t n_lines, hop;
     uint32_t pad_shift;  // floor(log2(hop * BPS)): one pad unit per 2^pad_shift bytes of span
+    uint32_t in_bytes;   // v2n_dma_kernel: bytes of a wave's landing buffer for this call's hop
     const void *tw, *win;
     float *out;
     int out_fmt;
 };
 
 typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+#ifndef V2N_DMA
+#define V2N_DMA 1  // 0: v2n_kernel for every hop (build.py --variant v2nold)
+#endif
 #ifndef V2N_OCC
 #define V2N_OCC 3  // waves per SIMD asked of the register allocator (147 registers: no spills at 3)
 #endif
@@ -158,6 +162,162 @@ __global__ __launch_bounds__(256, V2N_OCC) void v2n_kernel(const V2nArgs a) {
     }
 }
 
+// ---- the same blocks with the NEXT block's input span already on its way (round 5) ------------------------------------
+// v2n_kernel's waves spend 73 % of their cycles waiting (profiles/r05_n64_summary.md: twelve waves per CU do not cover a
+// block's load -> transform -> store chain), and a prefetch into registers had been measured slower (above).  Here the span
+// of block b + 1 is requested as soon as block b's samples have been picked out of the landing buffer, by LDS-DMA
+// (global_load_lds_dword: 256 contiguous bytes per wave instruction straight into LDS, no register, nothing for the
+// compiler to spill) into a landing buffer of the wave's own beside its exchange / staging region; it lands while block b is
+// transformed and stored, and the wait at the top of the loop is a COUNTED one that leaves block b's output stores in
+// flight.  A DMA instruction cannot pad inside its 256 bytes: line strides of >= 256 bytes only (cf32 from hop 32,
+// ci16 from hop 64, the byte formats from hop 128; what is below keeps v2n_kernel).  The span starts at the 4-byte boundary
+// below the first sample, so a cf32 sample never straddles a pad gap and is one aligned ds_read_b64.  One wave per
+// workgroup: the LDS (exchange region + landing buffer, sized per call from the hop) then fits eleven waves per CU at
+// 50 % overlap instead of eight with four-wave workgroups.
+__device__ __forceinline__ uint32_t v2n_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+// 4 bytes per lane from gsrc (per lane) to LDS lds_dst + 4 * lane (lds_dst wave-uniform); M0 saved and restored inside the
+// statement; the leading lgkmcnt(0): this wave's reads of the landing buffer have left the LDS queue
+__device__ __forceinline__ void v2n_glds4(const void *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void v2n_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int L> constexpr int v2n_ex_bytes() {  // exchange buffer of a block's lines / their output staging
+    using PL = Plan2<L>;
+    constexpr int LB = 64 / PL::T;
+    const int ex = LB * PL::LINE * 8, out = LB * (PL::N + 4) * 4;
+    return ((ex > out ? ex : out) + 15) & ~15;
+}
+
+template <int L, int KIND, bool BE>
+__global__ __launch_bounds__(64, V2N_OCC) void v2n_dma_kernel(const V2nArgs a) {
+    using PL = Plan2<L>;
+    using RW = Raw2<KIND>;
+    constexpr int N = PL::N, T = PL::T, E = PL::E, BPS = RW::BPS;
+    constexpr int LB = 64 / T, PADU = T * BPS, OUT_STRIDE = N + 4;
+    constexpr int STORES = LB * (N / 4) / 64;  // output store instructions of a full block
+    static_assert(STORES == 4, "the counted wait below");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    unsigned char *region = smem;                      // exchange, then output staging
+    unsigned char *landing = smem + v2n_ex_bytes<L>();  // the next block's input span
+    const int t = lane % T, j = lane / T;
+    const v2f *__restrict__ tw = static_cast<const v2f *>(a.tw);
+    v2f twl[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) twl[r] = tw[(r * t) & (N - 1)];
+    const float *win = static_cast<const float *>(a.win);
+    float w[E];
+    if (win) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) w[m] = win[t + m * T];
+    }
+    const uint32_t n_blocks = (a.n_lines + LB - 1) / LB;
+    const uint32_t per_wave = (n_blocks + gridDim.x - 1) / gridDim.x;
+    const uint32_t b0 = blockIdx.x * per_wave, b1 = b0 + per_wave < n_blocks ? b0 + per_wave : n_blocks;
+    if (b0 >= b1) return;
+    const uint32_t line_bytes = a.hop * BPS, psh = a.pad_shift;  // psh >= 8 (the launcher's condition)
+    auto padded = [&](uint32_t x) -> uint32_t { return x + (x >> psh) * (uint32_t)PADU; };
+    const uint32_t landing_lds = v2n_lds_addr(landing);
+    // request block b's span: dword 64 c + lane of it to landing + padded(256 c) + 4 lane
+    auto request = [&](uint32_t b) {
+        const uint32_t l0 = b * LB;
+        const uint32_t nb = a.n_lines - l0 < (uint32_t)LB ? a.n_lines - l0 : (uint32_t)LB;
+        const uint8_t *first = a.iq + (uint64_t)l0 * line_bytes;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 3u);
+        const uint32_t dwords = (mis + (nb - 1) * line_bytes + (uint32_t)N * BPS + 3u) / 4u;
+        const uint8_t *g = first - mis + 4u * (uint32_t)lane;
+        for (uint32_t c = 0; c * 64u < dwords; ++c)
+            if (c * 64u + (uint32_t)lane < dwords) v2n_glds4(g + 256u * c, landing_lds + padded(256u * c));
+    };
+    request(b0);
+    bool full_prev = false;  // the previous block issued STORES output stores behind this block's request
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t l0 = b * LB;
+        const uint32_t nb = a.n_lines - l0 < (uint32_t)LB ? a.n_lines - l0 : (uint32_t)LB;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(a.iq + (uint64_t)l0 * line_bytes) & 3u);
+        // this block's span has landed; the previous block's output stores (younger) may still be in flight
+        if (full_prev) v2n_vm_wait<STORES>();
+        else v2n_vm_wait<0>();
+        v2_sync<L>();
+        v2f v[E];
+        const uint32_t base = mis + (uint32_t)j * line_bytes + (uint32_t)t * BPS;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const unsigned char *p = landing + padded(base + (uint32_t)(m * T * BPS));
+            typename RW::type r;
+            if constexpr (BPS == 8) r = *reinterpret_cast<const typename RW::type *>(p);  // 8-byte aligned: mis = 0 for cf32
+            else if constexpr (BPS == 4) r = *reinterpret_cast<const uint32_t *>(p);
+            else r = *reinterpret_cast<const uint16_t *>(p);
+            v[m] = RW::dec(BE ? RW::swap(r) : r);  // SMH:87-91 byte order
+        }
+        if (b + 1 < b1) request(b + 1);  // (its lgkmcnt(0): the picks above have been read)
+        if (win) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};
+        }
+        v2_fft<L>(v, t, reinterpret_cast<v2f *>(region) + (size_t)j * PL::LINE, static_cast<const v2f *>(nullptr), twl);
+        float d[E];
+        constexpr bool BOUNDED = KIND != K_CF32;
+        if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, BOUNDED, E>(v, RW::SCALE, d);
+        else v2_epilogue<false, BOUNDED, E>(v, RW::SCALE, d);
+        v2_sync<L>();  // the exchange has been read: the region becomes the output staging
+        float *stage = reinterpret_cast<float *>(region);
+#pragma unroll
+        for (int m = 0; m < E; ++m) stage[j * OUT_STRIDE + ((t + m * T + N / 2) & (N - 1))] = d[m];  // SS:78
+        v2_sync<L>();
+        float *dst = a.out + (uint64_t)l0 * N;
+        if (nb == (uint32_t)LB) {  // exactly STORES store instructions (the counted wait relies on it)
+#pragma unroll
+            for (int i = 0; i < STORES; ++i) {
+                const uint32_t c = (uint32_t)lane + 64u * i;
+                const uint32_t row = c / (uint32_t)(N / 4), col = (c % (uint32_t)(N / 4)) * 4u;
+                const vu4 u = *reinterpret_cast<const vu4 *>(stage + row * OUT_STRIDE + col);
+                __builtin_nontemporal_store(u, reinterpret_cast<vu4 *>(dst) + c);
+            }
+            full_prev = true;
+        } else {
+            const uint32_t out_chunks = nb * (uint32_t)(N / 4);
+            for (uint32_t c = (uint32_t)lane; c < out_chunks; c += 64u) {
+                const uint32_t row = c / (uint32_t)(N / 4), col = (c % (uint32_t)(N / 4)) * 4u;
+                const vu4 u = *reinterpret_cast<const vu4 *>(stage + row * OUT_STRIDE + col);
+                __builtin_nontemporal_store(u, reinterpret_cast<vu4 *>(dst) + c);
+            }
+            full_prev = false;
+        }
+        v2_sync<L>();  // the staging has been read: the next block's exchange may be written
+    }
+}
+
+// bytes of the landing buffer for one hop: the padded span at its worst misalignment
+template <int L, int BPS> uint32_t v2n_landing_bytes(uint32_t hop, uint32_t psh) {
+    using PL = Plan2<L>;
+    constexpr uint32_t LB = 64 / PL::T, PADU = PL::T * BPS;
+    const uint32_t span = 3u + (LB - 1) * hop * BPS + (uint32_t)PL::N * BPS;
+    const uint32_t padded = ((span + 255u) & ~255u) + ((span >> psh) + 2u) * PADU;  // whole 256-byte pieces land
+    return (padded + 15u) & ~15u;
+}
+
+template <int L, int KIND, bool BE> hipError_t v2n_dma_launch(V2nArgs a, int n_cu, hipStream_t s) {
+    using PL = Plan2<L>;
+    using RW = Raw2<KIND>;
+    constexpr int LB = 64 / PL::T;
+    a.in_bytes = v2n_landing_bytes<L, RW::BPS>(a.hop, a.pad_shift);
+    const size_t lds = (size_t)v2n_ex_bytes<L>() + a.in_bytes;
+    auto kern = v2n_dma_kernel<L, KIND, BE>;
+    const uint32_t n_blocks = (a.n_lines + LB - 1) / LB;
+    uint32_t wgs = n_blocks;  // one wave each; enough to fill the chip a few times over, consecutive blocks per wave
+    const uint32_t cap = (uint32_t)n_cu * 64u;
+    if (wgs > cap) wgs = cap;
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int L, int KIND, bool BE> hipError_t v2n_launch(const V2nArgs &a, int n_cu, hipStream_t s) {
     using PL = Plan2<L>;
     using RW = Raw2<KIND>;
@@ -179,10 +339,11 @@ template <int L, int KIND, bool BE> hipError_t v2n_launch(const V2nArgs &a, int 
 }
 
 template <int L, int KIND> hipError_t v2n_launch_be(const V2nArgs &a, int be, int n_cu, hipStream_t s) {
+    const bool dma = V2N_DMA && a.pad_shift >= 8;  // line stride >= 256 bytes (v2n_dma_kernel)
     if constexpr (KIND == K_CF32 || KIND == K_CI16) {
-        if (be) return v2n_launch<L, KIND, true>(a, n_cu, s);
+        if (be) return dma ? v2n_dma_launch<L, KIND, true>(a, n_cu, s) : v2n_launch<L, KIND, true>(a, n_cu, s);
     }
-    return v2n_launch<L, KIND, false>(a, n_cu, s);
+    return dma ? v2n_dma_launch<L, KIND, false>(a, n_cu, s) : v2n_launch<L, KIND, false>(a, n_cu, s);
 }
 
 template <int L> hipError_t v2n_launch_kind(const V2nArgs &a, int kind, int be, int n_cu, hipStream_t s) {
