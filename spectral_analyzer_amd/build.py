@@ -235,6 +235,9 @@ VARIANTS = _unique([
     ("schilp", (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip"])),
     ("schb0", (["-mllvm", "-amdgpu-schedule-metric-bias=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip"])),
     ("schtrk", (["-mllvm", "-amdgpu-use-amdgpu-trackers"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip"])),
+    # round 5, A/B: |X|^2 left to the compiler (its SLP vectorizer pairs two bins per v_pk_mul / v_pk_fma behind four v_mov)
+    # instead of the two spelled-out instructions per bin of spec_fft_pk.h
+    ("slpnorm", (["-DSPEC_PK_NORM_ASM=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip", "spec_k_v2q.hip", "spec_k_v2n.hip"])),
     # development aid: per-wave shader-clock stamps at the phase boundaries of the Welch kernels (tools/v2_timeline.py)
     ("v2stamp", (["-DSPEC_V2_STAMPS", "-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
     ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),

@@ -65,9 +65,33 @@ template <typename V> __device__ __forceinline__ void pk_dft4(V &x0, V &x1, V &x
     x1 = pk_add_mi(t1, d);   // t1 + (-i) d
     x3 = pk_sub_mi(t1, d);   // t1 - (-i) d
 }
-// |a|^2 with scalar mul + fma: two instructions per bin.  (Left as v2f arithmetic hipcc packs two
-// bins per v_pk_mul_f32 and then spends four v_mov on the transposition: 3.5 per bin.)
-__device__ __forceinline__ float pk_norm(v2f a) { return __builtin_fmaf(a.x, a.x, a.y * a.y); }
+// |a|^2 = fma(x, x, y y) with scalar mul + fma: two instructions per bin.  Spelled as instructions since round 5: written as
+// __builtin_fmaf(a.x, a.x, a.y * a.y) the SLP vectorizer of ROCm 7.2's hipcc pairs two BINS into one v_pk_mul_f32 + v_pk_fma_f32
+// and spends four v_mov on gathering their x and y halves -- three instructions per bin instead of two (16 of the 420 vector
+// instructions of a 4096-point line, 32 of a 32-point thread's).  Same two roundings, bit-identical results.
+#ifndef SPEC_PK_NORM_ASM
+#define SPEC_PK_NORM_ASM 1  // 0: the compiler's form (build.py --variant slpnorm)
+#endif
+__device__ __forceinline__ float pk_norm(v2f a) {
+#if SPEC_PK_NORM_ASM
+    float r;
+    asm("v_mul_f32_e32 %0, %1, %1" : "=v"(r) : "v"(a.y));
+    asm("v_fmac_f32_e32 %0, %1, %1" : "+v"(r) : "v"(a.x));
+    return r;
+#else
+    return __builtin_fmaf(a.x, a.x, a.y * a.y);
+#endif
+}
+// acc + |a|^2 = fma(x, x, fma(y, y, acc)): the Welch sums (two chained FMAs per point; the compiler's form costs the same v_mov pairs)
+__device__ __forceinline__ float pk_norm_acc(v2f a, float acc) {
+#if SPEC_PK_NORM_ASM
+    asm("v_fmac_f32_e32 %0, %1, %1" : "+v"(acc) : "v"(a.y));
+    asm("v_fmac_f32_e32 %0, %1, %1" : "+v"(acc) : "v"(a.x));
+    return acc;
+#else
+    return __builtin_fmaf(a.x, a.x, __builtin_fmaf(a.y, a.y, acc));
+#endif
+}
 __device__ __forceinline__ double pk_norm(v2d a) { return __builtin_fma(a.x, a.x, a.y * a.y); }
 
 template <typename V> __device__ __forceinline__ void pk_dft2(V &a, V &b) {

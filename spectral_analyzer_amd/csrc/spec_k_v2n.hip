@@ -142,8 +142,7 @@ __global__ __launch_bounds__(256, V2N_OCC) void v2n_kernel(const V2nArgs a) {
         v2_fft<L>(v, t, reinterpret_cast<v2f *>(region) + (size_t)j * PL::LINE, static_cast<const v2f *>(nullptr), twl);
         float d[E];
         constexpr bool BOUNDED = KIND != K_CF32;
-        if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, BOUNDED, E>(v, RW::SCALE, d);
-        else v2_epilogue<false, BOUNDED, E>(v, RW::SCALE, d);
+        v2_epilogue<BOUNDED, E>(v, RW::SCALE, a.out_fmt == OUT_DB20_F32, d);
         v2_sync<L>();  // the exchange has been read: the region becomes the output staging
         float *stage = reinterpret_cast<float *>(region);
 #pragma unroll
@@ -264,8 +263,7 @@ __global__ __launch_bounds__(64, V2N_OCC) void v2n_dma_kernel(const V2nArgs a) {
         v2_fft<L>(v, t, reinterpret_cast<v2f *>(region) + (size_t)j * PL::LINE, static_cast<const v2f *>(nullptr), twl);
         float d[E];
         constexpr bool BOUNDED = KIND != K_CF32;
-        if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, BOUNDED, E>(v, RW::SCALE, d);
-        else v2_epilogue<false, BOUNDED, E>(v, RW::SCALE, d);
+        v2_epilogue<BOUNDED, E>(v, RW::SCALE, a.out_fmt == OUT_DB20_F32, d);
         v2_sync<L>();  // the exchange has been read: the region becomes the output staging
         float *stage = reinterpret_cast<float *>(region);
 #pragma unroll

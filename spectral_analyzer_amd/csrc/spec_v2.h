@@ -352,11 +352,10 @@ __device__ __forceinline__ void v2_fft(V (&v)[Plan2<L>::E], int t, V *lds, const
 // 20 log10(|X| + 1e-10) of the spectrum
 // scale * v (SS:80-81), one range test per thread
 // BOUNDED: the input format cannot overflow |X|^2 in fp32 (integer samples): no upper range test
+// p = |X|^2 of every bin, formed by the caller BEFORE it branches on the output format (v2_epilogue below): pk_norm is two
+// spelled-out instructions per bin, which the compiler does not merge across the two arms of that branch
 template <bool DB, bool BOUNDED, int E>
-__device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, float (&d)[E]) {
-    float p[E];
-#pragma unroll
-    for (int m = 0; m < E; ++m) p[m] = pk_norm(v[m]);
+__device__ __forceinline__ void v2_epilogue_p(const v2f (&v)[E], const float (&p)[E], float scale, float (&d)[E]) {
     const float s2 = scale * scale;
     if constexpr (!DB) {
 #pragma unroll
@@ -386,6 +385,16 @@ __device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, floa
             for (int m = 0; m < E; ++m) d[m] = db20(cx<float>{v[m].x * scale, v[m].y * scale});
         }
     }
+}
+
+// db: OUT_DB20_F32, otherwise |X|^2 (OUT_POW_F32)
+template <bool BOUNDED, int E>
+__device__ __forceinline__ void v2_epilogue(const v2f (&v)[E], float scale, bool db, float (&d)[E]) {
+    float p[E];
+#pragma unroll
+    for (int m = 0; m < E; ++m) p[m] = pk_norm(v[m]);
+    if (db) v2_epilogue_p<true, BOUNDED, E>(v, p, scale, d);
+    else v2_epilogue_p<false, BOUNDED, E>(v, p, scale, d);
 }
 
 #ifndef SPEC_V2_WIN_LDS
@@ -580,14 +589,13 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
             if (line < my_lines) {
 #pragma unroll
                 for (int m = 0; m < E; ++m)  // two chained FMAs per point (as a sum of pk_norm: multiply, FMA and an add)
-                    acc[m] = __builtin_fmaf(v[m].x, v[m].x, __builtin_fmaf(v[m].y, v[m].y, acc[m]));
+                    acc[m] = pk_norm_acc(v[m], acc[m]);
             }
             V2_STAMP(sp, 15);
         } else {
             float d[E];
             constexpr bool BOUNDED = KIND != K_CF32;
-            if (a.out_fmt == OUT_DB20_F32) v2_epilogue<true, BOUNDED, E>(v, RW::SCALE, d);
-            else v2_epilogue<false, BOUNDED, E>(v, RW::SCALE, d);
+            v2_epilogue<BOUNDED, E>(v, RW::SCALE, a.out_fmt == OUT_DB20_F32, d);
             if constexpr (MODE == 2) {
                 const int row_off = (int)(line * a.out_stride * 4u);
 #pragma unroll

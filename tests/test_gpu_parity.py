@@ -409,6 +409,30 @@ def test_short_lines_every_hop_and_tail(svc, oracle, nfft, datatype, window):
     check_fp32(g, oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines, window), nfft)
 
 
+@pytest.mark.parametrize("nfft,datatype,hop_div,window", [(64, "cf32_le", 2, sa.WIN_RECT), (64, "ci16_be", 1, sa.WIN_HANN),
+                                                         (128, "cf32_be", 2, sa.WIN_RECT), (128, "ci16_le", 1, sa.WIN_RECT),
+                                                         (128, "cu8", 1, sa.WIN_HANN)])
+def test_short_lines_many_blocks_per_wave(svc, oracle, nfft, datatype, hop_div, window):
+    """v2n_dma_kernel (spec_k_v2n.hip) requests the NEXT block's span by LDS-DMA while the current block is transformed and
+    waits for it with a counted s_waitcnt that leaves the current block's four output stores in flight.  That loop only
+    turns when a wave owns several blocks: more than 64 one-wave workgroups per CU, i.e. > 262 144 lines of 64 points or
+    > 131 072 of 128.  Every line of such a call against the oracle (MC:980-999 around SS:33-85), with a partial last
+    block and two lines past the end of the recording."""
+    import torch
+    hop = nfft // hop_div
+    lb = 64 // (nfft // 16)
+    n_lines = 256 * 64 * lb + 40 * lb + 3           # every wave of a 256-CU device at least one block, some two; tail of 3
+    n = (n_lines - 1) * hop + nfft
+    iq = oracle.synth_iq(datatype, seed=nfft + hop_div, first_sample=3, n_samples=n)
+    ref = oracle.waterfall(iq, 0, datatype, nfft, hop, n_lines + 2, window)
+    got = svc.compute_waterfall(torch.from_numpy(iq).cuda(), 0, nfft, datatype, n_lines + 2, hop=hop, window=window)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert np.all(got[n_lines:] == -150.0) and np.all(ref[n_lines:] == -150.0)
+    for lo in range(0, n_lines, 1 << 16):           # (bounded temporaries)
+        check_fp32(got[lo:lo + (1 << 16)], ref[lo:lo + (1 << 16)], nfft)
+
+
 @pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be"])
 @pytest.mark.parametrize("nfft", [64, 128])
 def test_short_lines_start_at_4_mod_8(svc, oracle, nfft, datatype):

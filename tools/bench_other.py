@@ -43,6 +43,10 @@ if "sizes" in which:
     spectro("cf32_le", 4096, 2048, 28, window=1, label="4096/2048 cf32 hann")
     spectro("cu8", 4096, 2048, 28, label="4096/2048 cu8")
     spectro("cf32_be", 4096, 2048, 28, label="4096/2048 cf32_be")
+if "refhop" in which:  # the reference's own call shape: hop = nfft (MC:984-985), every tick of its NFFT slider (main-scene.fxml:129-132)
+    for dt in ("cf32_le", "ci16_le"):
+        for lg in range(6, 17):
+            spectro(dt, 1 << lg, 1 << lg, 28 if lg < 13 else 29, label="%s n=%d hop=nfft" % (dt, 1 << lg))
 if "cfg5only" in which:
     spectro("cf64_le", 65536, 32768, 28, fmt=sa.OUT_DB20_F64, label="cfg5 65536/32768 cf64->f64 2^28")
 if "cfg5" in which:
