@@ -86,6 +86,37 @@ def store_hazard_findings(path: str):
     return findings
 
 
+def waterfall_findings(path: str):
+    """Waterfall loops in the device assembly `path`: a memory instruction whose scalar operand the compiler could not prove
+    uniform is wrapped in `v_readfirstlane / v_cmp_eq / s_and_saveexec / <access> / s_xor exec / s_cbranch_execnz` -- three vector
+    and five scalar instructions and a branch per access.  Rounds 1-5 shipped the headline kernel with eight of them per line
+    (the ping-pong line loop looked divergent to hipcc: spec_v2.h, `iters`); no kernel of the product needs one, so the product
+    build fails on a finding (experiment variants only report)."""
+    import re
+    lines, kern = [], None
+    for line in open(path):
+        if line.startswith("_Z") and ":" in line:
+            kern = line.split(":")[0]
+        lines.append((kern, line.strip()))
+    label_at = {}
+    for i, (k, s) in enumerate(lines):
+        m = re.match(r"(\.LBB\d+_\d+):", s)
+        if m:
+            label_at[(k, m.group(1))] = i
+    count = {}
+    for i, (k, s) in enumerate(lines):
+        m = re.match(r"s_cbranch_execnz\s+(\.LBB\d+_\d+)", s)
+        if not m:
+            continue
+        j = label_at.get((k, m.group(1)))
+        if j is None or j > i or i - j > 40:
+            continue
+        body = [t for _, t in lines[j:i]]
+        if any(t.startswith("v_readfirstlane") for t in body) and any(re.match(r"(buffer|global|flat|ds)_", t) for t in body):
+            count[k] = count.get(k, 0) + 1
+    return ["%s: %d waterfall loop(s)" % (k[:100], n) for k, n in sorted(count.items())]
+
+
 def kernel_spills(path: str):
     """{mangled kernel name: spilled vector registers} from the metadata of a device assembly file."""
     import re
@@ -130,12 +161,17 @@ def _compile(src: str, objdir: str, extra) -> str:
     if not os.path.exists(asm):
         raise RuntimeError("no device assembly for %s (expected %s): the ISA lint cannot run" % (src, asm))
     bad = store_hazard_findings(asm)
+    wf = waterfall_findings(asm)
     spills = kernel_spills(asm)
     for f in os.listdir(objdir):  # the other temporaries (bitcode, preprocessed source: hundreds of MB over all units)
         if f.startswith(stem + "-") or f.startswith(stem + ".hip-"):
             os.remove(os.path.join(objdir, f))   # (the device assembly too, once linted below: 120 MB over all units)
     if bad:
         raise RuntimeError("ISA lint (store-data hazard, build.py store_hazard_findings) on %s:\n%s" % (src, "\n".join(bad[:20])))
+    if wf and not extra:
+        raise RuntimeError("ISA lint (waterfall loops, build.py waterfall_findings) on %s:\n%s" % (src, "\n".join(wf[:20])))
+    if wf:
+        print("note: %s (%s): %s" % (src, " ".join(extra), "; ".join(wf[:4])))
     with open(os.path.splitext(obj)[0] + ".spills", "w") as f:  # which kernels of this unit spill (tests/test_abi.py reads the product's)
         for k, n in sorted(spills.items()):
             f.write("%s %d\n" % (k, n))
@@ -159,7 +195,7 @@ def _toolchain() -> str:
 
 def _stamp(extra) -> str:
     """What a library was built with: the product flags plus any experiment flags, and the toolchain."""
-    return " ".join([*FLAGS, *extra]) + " | " + _toolchain() + " | isa-lint: store hazard"
+    return " ".join([*FLAGS, *extra]) + " | " + _toolchain() + " | isa-lint: store hazard, waterfall loops"
 
 
 # named variants: what they are compiled with, and which translation units the flags touch (the others are taken from
@@ -238,6 +274,9 @@ VARIANTS = _unique([
     # round 5, A/B: |X|^2 left to the compiler (its SLP vectorizer pairs two bins per v_pk_mul / v_pk_fma behind four v_mov)
     # instead of the two spelled-out instructions per bin of spec_fft_pk.h
     ("slpnorm", (["-DSPEC_PK_NORM_ASM=0"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2r.hip", "spec_k_v2h.hip", "spec_k_v2q.hip", "spec_k_v2n.hip"])),
+    # round 5, A/B: the line loop of the whole-workgroup kernels with the trip count left in a VGPR (rounds 1-5): hipcc wraps every
+    # load of the cf32 ping-pong kernels (2048 ... 16384 points, 50 % overlap, no window) in a waterfall loop
+    ("v2wfall", (["-DSPEC_V2_VECTOR_TRIP=1"], ["spec_k_v2s.hip", "spec_k_v2r.hip"])),
     # development aid: per-wave shader-clock stamps at the phase boundaries of the Welch kernels (tools/v2_timeline.py)
     ("v2stamp", (["-DSPEC_V2_STAMPS", "-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
     ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),

@@ -523,14 +523,25 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
     // sub-lines whose run lies past the end read zeros and store nothing (descriptor bounds)
     const uint32_t my_first = q * a.run;
     const uint32_t my_lines = my_first >= lines_wg ? 0 : (lines_wg - my_first < a.run ? lines_wg - my_first : a.run);
-    const uint32_t iters = PL::WAVE_LOCAL ? a.run : my_lines;  // whole-workgroup lines: LPW == 1
-
-    if constexpr (PL::NPASS > 2) __syncthreads();  // LDS twiddle tables visible
-
     // 50 % overlap, cf32 spectrogram: the two register halves swap roles from one line to the next
     // (two copies of the loop body) instead of being moved; every other variant shifts the
     // registers down (the doubled body costs them 8-40 spilled VGPRs, more than the moves)
     constexpr bool PINGPONG = SH * 2 == E && KIND == K_CF32 && !HAS_WIN && MODE == 0;
+    // Whole-workgroup lines (LPW == 1, q == 0): the trip count is the same for every thread.  The ping-pong kernels SAY so
+    // (readfirstlane): hipcc cannot see it through tid / T, and with the second copy of the body under `if (line + 1 < iters)` it
+    // took the loop for a divergent one, kept the byte offset of the next line in a VGPR and wrapped every load of the line in a
+    // waterfall loop (v_readfirstlane / v_cmp / s_and_saveexec / load / s_xor / s_cbranch_execnz: three vector and five scalar
+    // instructions and a branch per load -- 24 of the 405 vector instructions of a 4096-point line, rounds 1-5; the build now
+    // fails on such a loop, build.py waterfall_findings).  The single-copy kernels never had one and keep their code as measured
+    // (with a scalar trip count the 16384-point Welch kernel is scheduled differently and loses 2 %).
+#ifndef SPEC_V2_VECTOR_TRIP
+#define SPEC_V2_VECTOR_TRIP 0  // 1: as in rounds 1-5 (build.py --variant v2wfall, for the A/B)
+#endif
+    const uint32_t iters = PL::WAVE_LOCAL ? a.run  // whole-workgroup lines: LPW == 1
+                           : PINGPONG && !SPEC_V2_VECTOR_TRIP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)my_lines) : my_lines;
+
+    if constexpr (PL::NPASS > 2) __syncthreads();  // LDS twiddle tables visible
+
 #ifdef SPEC_V2_STAMPS
     // [wave][segment 0..2][16] words behind everything else in LDS; a.out_stride = first stamped segment, a.sel = where they go
     uint32_t *const stamp0 = reinterpret_cast<uint32_t *>(smem + ((p2_lds_bytes<L>() + ((size_t)N / 4 + 1) * 4 + 15) & ~(size_t)15)) + (tid >> 6) * 48;
@@ -551,8 +562,16 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
 #pragma unroll
                 for (int m = 0; m < E / 2; ++m) {  // n = t + m T < N/2;  w[N/2 - n] = 1 - w[n],  w[n + N/2] = 1 - w[n]
                     const float x = m < E / 4 ? q0[m * T] : q1[(E / 2 - 1 - m) * T];
-                    w[m] = m < E / 4 ? x : 1.0f - x;
-                    w[m + E / 2] = m < E / 4 ? 1.0f - x : x;
+                    // 1 - x spelled as an instruction: left to hipcc, its SLP vectorizer pairs two of these subtractions into a
+                    // v_pk_add_f32 behind two v_mov and unpacks the result with two more (40 instructions per line instead of 16)
+                    float y;
+#if SPEC_PK_NORM_ASM
+                    asm("v_sub_f32_e32 %0, 1.0, %1" : "=v"(y) : "v"(x));
+#else
+                    y = 1.0f - x;  // (build.py --variant slpnorm: the compiler's form, for the A/B)
+#endif
+                    w[m] = m < E / 4 ? x : y;
+                    w[m + E / 2] = m < E / 4 ? y : x;
                 }
             } else if (ones || p2_rows<L>()) {  // (the row plan is launched with the Hann window or the table of ones only: v2_launch_n)
 #pragma unroll
