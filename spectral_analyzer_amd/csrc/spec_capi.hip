@@ -79,6 +79,7 @@ struct spec_ctx {
     int64_t opt_large_single = 1;  // 32768-point fp32 lines in one workgroup (spec_k_v2h.hip); 0: the four-step path
     int64_t opt_pair_interleave = 1;  // the paired kernel's line order: the pairs of an XCD walk one block of lines together (spec_k_v2q.hip)
     int64_t opt_large_pair = 1;    // 65536-point fp32 lines by pairs of single-workgroup kernels (spec_k_v2q.hip); 0: the four-step team kernel
+    int64_t opt_coop_256 = 2;  // "coop_256": 256-point lines through the wave-cooperative kernel of spec_k_v2n.hip: 2 where measured faster (coop_256_rule), 1 always, 0 never
     int64_t opt_small_single = 2;  // 8192-point fp32 lines through the same kernel (16 points per thread and half): 2 where measured faster, 1 always, 0 never
     int64_t opt_mid_single = 2;    // 16384-point fp32 lines through the same kernel: 2 where measured faster (run_lines), 1 always, 0 never
     int64_t opt_debug_twiddle_bits = 0;  // test hook: twiddle tables built from now on lose this many mantissa bits (tests/test_gpu_parity.py mutation test)
@@ -356,6 +357,19 @@ spec_status spec_sync(spec_ctx *c) {
 
 void *spec_stream(const spec_ctx *c) { return c ? static_cast<void *>(c->stream) : nullptr; }
 
+// 256-point lines: the packed family's kernel (register reuse of the overlap, 16 lanes per line) or the wave-cooperative kernel
+// of the 64- / 128-point lines (a wave reads the span of four lines with 16 bytes per lane into LDS and stores them the same way).
+// Measured cell by cell on one box (tools/bench_coop.py, profiles/r05_coop256.txt; fractions of 8 TB/s, family -> cooperative):
+//   cu8 / ci8 (2-byte samples: the family's lane groups read 32 bytes at a time)   every hop and window   1.17x ... 1.37x
+//   big-endian files: with a window, or at a hop other than N and N/2 (level there: 0.96x ... 1.05x)          1.16x ... 1.52x
+//   little-endian cf32 / ci16 at a hop the family has no register-reuse variant for (not N, N/2, N/4)       1.07x ... 1.17x
+//   little-endian cf32 / ci16 at hop = N, N/2, N/4                                                          0.85x ... 1.03x: the family stays
+static bool coop_256_rule(int kind, int be, uint32_t hop, bool win) {
+    if (kind == K_CU8 || kind == K_CI8) return true;
+    if (be) return win || (hop != 128 && hop != 256);
+    return hop != 256 && hop != 128 && hop != 64;
+}
+
 spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     if (!c) return SPEC_EINVAL;
     Enter g(c);
@@ -392,6 +406,7 @@ spec_status spec_set_option(spec_ctx *c, const char *key, int64_t value) {
     else if (!strcmp(key, "pair_interleave")) c->opt_pair_interleave = value != 0;
     else if (!strcmp(key, "mid_single")) c->opt_mid_single = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "small_single")) c->opt_small_single = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (!strcmp(key, "coop_256")) c->opt_coop_256 = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (!strcmp(key, "multi_verify")) c->opt_multi_verify = value != 0;
     else if (!strcmp(key, "multi_verify_corrupt")) c->opt_multi_verify_corrupt = value != 0;
     else if (!strcmp(key, "render_fused")) c->opt_render_fused = value != 0;
@@ -407,7 +422,7 @@ spec_status spec_get_option(spec_ctx *c, const char *key, int64_t *value) {
     struct { const char *k; int64_t v; } tab[] = {
         {"force_generic", c->opt_force_generic}, {"lines_per_wg", c->opt_lines_per_wg}, {"large_chunk_mb", c->opt_large_chunk_mb},
         {"stage_chunk_mb", c->opt_stage_chunk_mb}, {"rec_pread", c->opt_rec_pread}, {"welch_two_pass", c->opt_welch_two_pass}, {"debug_twiddle_bits", c->opt_debug_twiddle_bits}, {"welch_rows", c->opt_welch_rows},
-        {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"large_pair", c->opt_large_pair}, {"pair_interleave", c->opt_pair_interleave}, {"mid_single", c->opt_mid_single}, {"small_single", c->opt_small_single},
+        {"large_team", c->opt_large_team}, {"large_ring", c->opt_large_ring}, {"large_wg", c->opt_large_wg}, {"large_single", c->opt_large_single}, {"large_pair", c->opt_large_pair}, {"pair_interleave", c->opt_pair_interleave}, {"mid_single", c->opt_mid_single}, {"small_single", c->opt_small_single}, {"coop_256", c->opt_coop_256},
         {"large_block", c->opt_large_block}, {"render_fused", c->opt_render_fused}, {"readahead_lines", c->opt_readahead_lines},
         {"large_team_fake_abort", c->opt_team_fake_abort}, {"large_team_disabled", c->team_disabled ? 1 : 0},
         {"multi_verify", c->opt_multi_verify}, {"multi_verify_corrupt", c->opt_multi_verify_corrupt}, {"multi_peer_access", c->multi_peer_access}, {"multi_verified", c->multi_verified},
@@ -797,7 +812,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
         }
         return SPEC_OK;
     }
-    if (!f64 && !d_sel && !c->opt_force_generic && v2n_applicable(log2n, a.kind, a.out_fmt, n_lines, hop, d_first)) {
+    if (!f64 && !d_sel && !c->opt_force_generic && v2n_applicable(log2n, a.kind, a.out_fmt, n_lines, hop, d_first,
+                                                                    c->opt_coop_256 == 1 || (c->opt_coop_256 == 2 && coop_256_rule(a.kind, a.be, hop, a.win != nullptr)) ? 8 : 7)) {
         // 64 / 128 points: wave-cooperative I/O around the packed FFT core (spec_k_v2n.hip)
         uint64_t done = 0;
         while (done < n_lines) {

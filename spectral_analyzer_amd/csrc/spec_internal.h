@@ -85,7 +85,7 @@ bool v3d_applicable(int log2n, int kind, uint64_t n_lines, uint32_t hop);
 hipError_t launch_v3d_spectro(const WfArgs &w, int log2n, uint32_t run, hipStream_t s);
 // 64- and 128-point lines (spec_k_v2n.hip): a wave works on 16 / 8 consecutive lines at a time, all global traffic in
 // 16-byte-per-lane pieces through its own LDS region; `first` = address of the first line's first byte (alignment)
-bool v2n_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop, const void *first);
+bool v2n_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop, const void *first, int max_log2n);
 hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t s);
 // 32768- (and, as an option, 16384-) point fp32 lines in one workgroup (spec_k_v2h.hip): w.tw = v2f W_N table, tw_half = v2f
 // W_(N/2) table, w.win = non-null for the Hann window; `run` consecutive lines per workgroup

@@ -357,8 +357,8 @@ template <int L> hipError_t v2n_launch_kind(const V2nArgs &a, int kind, int be, 
 }  // namespace
 
 // 64 / 128 points, fp32 outputs, hop between 16 bytes' worth of samples and N, input aligned to min(4, bytes per sample)
-bool v2n_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop, const void *first) {
-    if (log2n != 6 && log2n != 7) return false;
+bool v2n_applicable(int log2n, int kind, int out_fmt, uint64_t n_lines, uint32_t hop, const void *first, int max_log2n) {
+    if (log2n < 6 || log2n > max_log2n || log2n > 8) return false;
     if (kind != K_CF32 && kind != K_CI16 && kind != K_CU8 && kind != K_CI8) return false;
     if (out_fmt != OUT_DB20_F32 && out_fmt != OUT_POW_F32) return false;
     const uint32_t bps = kind == K_CF32 ? 8u : kind == K_CI16 ? 4u : 2u;
@@ -374,7 +374,8 @@ hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t 
     uint32_t lb = w.hop * w.bps, sh = 0;
     while ((2u << sh) <= lb) ++sh;
     a.pad_shift = sh;
-    return log2n == 6 ? v2n_launch_kind<6>(a, w.kind, w.be, n_cu, s) : v2n_launch_kind<7>(a, w.kind, w.be, n_cu, s);
+    return log2n == 6 ? v2n_launch_kind<6>(a, w.kind, w.be, n_cu, s) : log2n == 7 ? v2n_launch_kind<7>(a, w.kind, w.be, n_cu, s)
+                                                                                    : v2n_launch_kind<8>(a, w.kind, w.be, n_cu, s);
 }
 
 }  // namespace specgpu

@@ -375,12 +375,23 @@ def test_partial_last_workgroup_writes_nothing_past_the_tile(svc, oracle, case):
 
 
 # ---- 64- and 128-point lines: the wave-cooperative kernel (spec_k_v2n.hip) ------------------------------------------
-@pytest.mark.parametrize("nfft", [64, 128])
+@pytest.fixture
+def coop(svc, request):
+    """256-point lines take the cooperative kernel only in the cells of coop_256_rule (spec_capi.hip): forced here, so that every
+    case of these tests runs through it, and put back."""
+    nfft = request.node.callspec.params.get("nfft")
+    if nfft == 256:
+        svc.set_option("coop_256", 1)
+    yield
+    svc.set_option("coop_256", 2)
+
+
+@pytest.mark.parametrize("nfft", [64, 128, 256])
 @pytest.mark.parametrize("datatype,window", [("cf32_le", sa.WIN_RECT), ("cf32_be", sa.WIN_HANN), ("ci16_le", sa.WIN_HANN),
                                              ("ci16_be", sa.WIN_RECT), ("cu8", sa.WIN_RECT), ("ci8", sa.WIN_HANN)])
-def test_short_lines_every_hop_and_tail(svc, oracle, nfft, datatype, window):
-    """The low end of the reference's NFFT slider (main-scene.fxml:129-132).  A wave works on 16 (8) consecutive lines
-    at a time through its own LDS region: every hop from 16 bytes' worth of samples up to nfft (the reference's own),
+def test_short_lines_every_hop_and_tail(svc, oracle, coop, nfft, datatype, window):
+    """The low end of the reference's NFFT slider (main-scene.fxml:129-132).  A wave works on 16 (8; 4 at 256 points) consecutive
+    lines at a time through its own LDS region: every hop from 16 bytes' worth of samples up to nfft (the reference's own),
     line counts that are not a multiple of the block (tail blocks), a start that is not 16-byte aligned, lines past the
     end of the recording (-150, MC:994-998), power output; below 16 bytes per hop and above nfft the generic kernel runs."""
     import torch
@@ -411,12 +422,13 @@ def test_short_lines_every_hop_and_tail(svc, oracle, nfft, datatype, window):
 
 @pytest.mark.parametrize("nfft,datatype,hop_div,window", [(64, "cf32_le", 2, sa.WIN_RECT), (64, "ci16_be", 1, sa.WIN_HANN),
                                                          (128, "cf32_be", 2, sa.WIN_RECT), (128, "ci16_le", 1, sa.WIN_RECT),
-                                                         (128, "cu8", 1, sa.WIN_HANN)])
-def test_short_lines_many_blocks_per_wave(svc, oracle, nfft, datatype, hop_div, window):
+                                                         (128, "cu8", 1, sa.WIN_HANN), (256, "cu8", 2, sa.WIN_RECT),
+                                                         (256, "cf32_le", 1, sa.WIN_HANN)])
+def test_short_lines_many_blocks_per_wave(svc, oracle, coop, nfft, datatype, hop_div, window):
     """v2n_dma_kernel (spec_k_v2n.hip) requests the NEXT block's span by LDS-DMA while the current block is transformed and
     waits for it with a counted s_waitcnt that leaves the current block's four output stores in flight.  That loop only
-    turns when a wave owns several blocks: more than 64 one-wave workgroups per CU, i.e. > 262 144 lines of 64 points or
-    > 131 072 of 128.  Every line of such a call against the oracle (MC:980-999 around SS:33-85), with a partial last
+    turns when a wave owns several blocks: more than 64 one-wave workgroups per CU, i.e. > 262 144 lines of 64 points,
+    > 131 072 of 128 or > 65 536 of 256.  Every line of such a call against the oracle (MC:980-999 around SS:33-85), with a partial last
     block and two lines past the end of the recording."""
     import torch
     hop = nfft // hop_div
@@ -429,13 +441,15 @@ def test_short_lines_many_blocks_per_wave(svc, oracle, nfft, datatype, hop_div, 
     torch.cuda.synchronize()
     got = got.cpu().numpy()
     assert np.all(got[n_lines:] == -150.0) and np.all(ref[n_lines:] == -150.0)
+    # the contract only: over 65 000 ... 260 000 lines the weak-bin maximum creeps past the flat regression tiers of the
+    # small deterministic cases (4.5e-3 dB at 1e-4 M seen here with the Hann window: docstring at the top of this file)
     for lo in range(0, n_lines, 1 << 16):           # (bounded temporaries)
-        check_fp32(got[lo:lo + (1 << 16)], ref[lo:lo + (1 << 16)], nfft)
+        check_fp32(got[lo:lo + (1 << 16)], ref[lo:lo + (1 << 16)], nfft, regression=False)
 
 
 @pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be"])
-@pytest.mark.parametrize("nfft", [64, 128])
-def test_short_lines_start_at_4_mod_8(svc, oracle, nfft, datatype):
+@pytest.mark.parametrize("nfft", [64, 128, 256])
+def test_short_lines_start_at_4_mod_8(svc, oracle, coop, nfft, datatype):
     """include/specgpu.h promises component alignment only: a cf32 recording may start 4 bytes into an 8-byte word (a
     4-byte header, a Welch stride of 4 mod 8).  In the 64- / 128-point kernel a sample's two words can then lie on either
     side of a pad gap of the wave's LDS span (round-3 advisor: mis = 4, hop = 32, N = 64, line 0, t = 3, m = 7): every

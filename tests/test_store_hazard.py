@@ -58,3 +58,49 @@ def test_the_lint_sees_the_unpadded_pattern(asm, tmp_path):
     found = check_store_hazard.check(hand)
     assert len(found) == 1 and found[0].startswith("_Zk")
     assert len(check_store_hazard.check(stripped)) >= len(check_store_hazard.check(asm))
+
+
+# ---- waterfall loops (build.py waterfall_findings) -------------------------------------------------------------------------
+WATERFALL = """_Zwf:
+\tv_add_u32_e32 v34, 0x4000, v46
+\ts_mov_b64 s[0:1], exec
+.LBB1_8:
+\tv_readfirstlane_b32 s2, v34
+\ts_nop 1
+\tv_cmp_eq_u32_e32 vcc, s2, v34
+\ts_and_saveexec_b64 vcc, vcc
+\tbuffer_load_dwordx2 v[32:33], v113, s[4:7], s2 offen nt
+\ts_xor_b64 exec, exec, vcc
+\ts_cbranch_execnz .LBB1_8
+\ts_mov_b64 exec, s[0:1]
+\ts_endpgm
+_Zplain:
+.LBB2_1:
+\tbuffer_load_dwordx2 v[32:33], v113, s[4:7], s2 offen nt
+\tv_readfirstlane_b32 s3, v1
+\ts_cbranch_scc1 .LBB2_1
+\ts_endpgm
+"""
+
+
+def test_the_build_lint_sees_a_waterfall_loop(tmp_path):
+    """The headline kernel shipped with eight of these per line for five rounds (spec_v2.h, `iters`): the loop around a memory
+    instruction whose scalar operand hipcc could not prove uniform.  The product build fails on one; here the detector itself."""
+    from spectral_analyzer_amd import build as hip_build
+    p = str(tmp_path / "wf.s")
+    open(p, "w").write(WATERFALL)
+    found = hip_build.waterfall_findings(p)
+    assert len(found) == 1 and found[0].startswith("_Zwf: 1 waterfall")
+
+
+def test_no_waterfall_loop_in_the_16_byte_store_kernels(asm):
+    from spectral_analyzer_amd import build as hip_build
+    assert hip_build.waterfall_findings(asm) == []
+
+
+def test_the_product_library_was_built_with_both_lints():
+    from spectral_analyzer_amd import build as hip_build
+    stamp = hip_build.LIB + ".flags"
+    if not os.path.exists(stamp):
+        pytest.skip("library not built")
+    assert "isa-lint: store hazard, waterfall loops" in open(stamp).read()
