@@ -277,6 +277,9 @@ VARIANTS = _unique([
     # round 5, A/B: the line loop of the whole-workgroup kernels with the trip count left in a VGPR (rounds 1-5): hipcc wraps every
     # load of the cf32 ping-pong kernels (2048 ... 16384 points, 50 % overlap, no window) in a waterfall loop
     ("v2wfall", (["-DSPEC_V2_VECTOR_TRIP=1"], ["spec_k_v2s.hip", "spec_k_v2r.hip"])),
+    # round 5, A/B: no wait for the first line's samples in front of the line loop (rounds 1-5): hipcc's wait counts at the loop
+    # header then cover the previous line's output stores as well
+    ("v2nowait", (["-DSPEC_V2_ENTRY_WAIT=0"], ["spec_k_v2s.hip", "spec_k_v2r.hip"])),
     # development aid: per-wave shader-clock stamps at the phase boundaries of the Welch kernels (tools/v2_timeline.py)
     ("v2stamp", (["-DSPEC_V2_STAMPS", "-DSPEC_V2_ROWS"], ["spec_k_v2w.hip", "spec_capi.hip"])),
     ("v3hhi", (["-DV3H_EARLY_LO_FIRST=0"], ["spec_k_v3h.hip"])),

@@ -637,6 +637,15 @@ __global__ __launch_bounds__(Plan2<L>::WG, OCC) void v2_kernel(const V2Args a) {
             }
         }
     };
+    // The first line's samples have landed BEFORE the loop is entered (a wait the first transform needs anyway).  Without it
+    // hipcc's wait-count insertion merges the loop entry (16 / 32 loads in flight, no store) with the back edge (the next line's
+    // loads in flight BEHIND them the line's 16 output stores) into the smaller count of the two, and every line began with
+    // s_waitcnt vmcnt(0) ... vmcnt(12): it sat out the completion of the output stores it had issued an instant before
+    // (rounds 1-5; with the entry path empty the header waits are vmcnt(16 + k): the loads only).
+#ifndef SPEC_V2_ENTRY_WAIT
+#define SPEC_V2_ENTRY_WAIT 1  // 0: as in rounds 1-5 (build.py --variant v2nowait, for the A/B)
+#endif
+    if constexpr (SPEC_V2_ENTRY_WAIT != 0 && MODE != 1) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
     if constexpr (PINGPONG) {
         for (uint32_t line = 0; line < iters; line += 2) {
             do_line(line, std::integral_constant<int, 0>{});

@@ -47,6 +47,11 @@ if "refhop" in which:  # the reference's own call shape: hop = nfft (MC:984-985)
     for dt in ("cf32_le", "ci16_le"):
         for lg in range(6, 17):
             spectro(dt, 1 << lg, 1 << lg, 28 if lg < 13 else 29, label="%s n=%d hop=nfft" % (dt, 1 << lg))
+if "bytefmt" in which:  # the 2-byte formats against ci16 at the same sizes: lines/s should match where the kernel is not load-granularity bound
+    for lg in (9, 10, 11, 12):
+        for hop_div in (1, 2):
+            for dt in ("ci16_le", "cu8", "ci8"):
+                spectro(dt, 1 << lg, (1 << lg) // hop_div, 28)
 if "cfg5only" in which:
     spectro("cf64_le", 65536, 32768, 28, fmt=sa.OUT_DB20_F64, label="cfg5 65536/32768 cf64->f64 2^28")
 if "cfg5" in which:
