@@ -171,9 +171,8 @@ void *spec_stream(const spec_ctx *ctx);
  *                     than N/4, N/2, N; 8 ... 11 points of the roofline faster; level everywhere else), 1 = always, 0 = never
  *   "coop_256" = 2 | 1 | 0   256-point fp32 lines through the wave-cooperative kernel of the 64- / 128-point lines (a wave reads
  *                     the span of four consecutive lines with 16 bytes per lane into LDS and stores them the same way):
- *                     2 (default) = where it was measured faster than the family's kernel (cu8 / ci8: 1.17x ... 1.37x; big-endian
- *                     files except 50 % overlap without a window: up to 1.54x; little-endian cf32 / ci16 at hops other than
- *                     N, N/2, N/4: 1.07x ... 1.17x), 1 = always, 0 = never
+ *                     2 (default) = where it was measured faster than the family's kernel (cu8 / ci8: 1.17x ... 1.46x; cf32 / ci16
+ *                     at hops other than N, N/2, N/4: 1.07x ... 1.17x), 1 = always, 0 = never
  *   "large_pair" = 1 | 0 | 2   65536-point fp32 lines (the default dispatch, "large_team" = 1): 1 (default) = a PAIR of workgroups
  *                     per line, each a single-workgroup kernel on two of the four outputs of a radix-4 step taken in registers
  *                     (two 16384-point transforms each; nothing is handed over, nothing waits): 1.04x ... 5.3x the four-step

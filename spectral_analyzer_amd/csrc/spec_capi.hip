@@ -361,12 +361,11 @@ void *spec_stream(const spec_ctx *c) { return c ? static_cast<void *>(c->stream)
 // of the 64- / 128-point lines (a wave reads the span of four lines with 16 bytes per lane into LDS and stores them the same way).
 // Measured cell by cell on one box (tools/bench_coop.py, profiles/r05_coop256.txt; fractions of 8 TB/s, family -> cooperative):
 //   cu8 / ci8 (2-byte samples: the family's lane groups read 32 bytes at a time)   every hop and window   1.17x ... 1.37x
-//   big-endian files: with a window, or at a hop other than N and N/2 (level there: 0.96x ... 1.05x)          1.16x ... 1.52x
-//   little-endian cf32 / ci16 at a hop the family has no register-reuse variant for (not N, N/2, N/4)       1.07x ... 1.17x
-//   little-endian cf32 / ci16 at hop = N, N/2, N/4                                                          0.85x ... 1.03x: the family stays
+//   cf32 / ci16, either byte order, at a hop the family has no register-reuse variant for (not N, N/2, N/4)   1.07x ... 1.17x
+//   cf32 / ci16 at hop = N, N/2, N/4                                                                          0.85x ... 1.05x: the family stays
 static bool coop_256_rule(int kind, int be, uint32_t hop, bool win) {
     if (kind == K_CU8 || kind == K_CI8) return true;
-    if (be) return win || (hop != 128 && hop != 256);
+    (void)be; (void)win;  // (big-endian files have had the family's register-reuse variants since round 5: the same rule)
     return hop != 256 && hop != 128 && hop != 64;
 }
 

@@ -710,9 +710,9 @@ hipError_t v2_launch1(const V2Args &a, hipStream_t s) {
 
 // Instantiation matrix: register-reuse variants for hop = N/2 (50 % overlap) in every format, for
 // hop = N/4 (75 %) in cf32 / ci16 and in every Welch kernel; every other hop takes SH = 0 (the overlap then
-// comes from L2).  Big-endian files: the 50 %-overlap spectrogram without a window has its register-reuse
-// variant too (round 3: the raw registers hold the file's bytes, the swap happens at decode; it was 49 % of
-// the peak re-reading the overlap from L2), everything else one SH = 0 variant per mode.
+// comes from L2).  Big-endian files: the spectrogram kernels have the same register-reuse variants (the raw registers
+// hold the file's bytes, the swap happens at decode: 50 % overlap without a window since round 3, the windowed and the
+// 75 % ones since round 5), Welch and the redraw mode one SH = 0 variant each.
 // Welch always multiplies by a window table (all ones for the rectangular window).
 template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hipStream_t s) {
     constexpr int N = Plan2<L>::N, E = Plan2<L>::E;
@@ -721,7 +721,10 @@ template <int L, int KIND, int MODE> hipError_t v2_launch_sh(const V2Args &a, hi
         if (a.be) {
             if constexpr (MODE == 1) return v2_launch1<L, KIND, 0, true, 1, true>(a, s);
             else if constexpr (MODE == 0) {
-                if (a.hop == N / 2 && !a.win) return v2_launch1<L, KIND, E / 2, false, 0, true>(a, s);
+                // (round 5: the windowed 50 % and both 75 % variants as well -- re-reading the overlap from L2 these cells ran at
+                // 0.35 / 0.46 of 8 TB/s where the little-endian kernels reach 0.52 / 0.62: profiles/r05_cells.txt)
+                if (a.hop == N / 2) return a.win ? v2_launch1<L, KIND, E / 2, true, 0, true>(a, s) : v2_launch1<L, KIND, E / 2, false, 0, true>(a, s);
+                if (a.hop == N / 4) return a.win ? v2_launch1<L, KIND, E / 4, true, 0, true>(a, s) : v2_launch1<L, KIND, E / 4, false, 0, true>(a, s);
                 return a.win ? v2_launch1<L, KIND, 0, true, 0, true>(a, s) : v2_launch1<L, KIND, 0, false, 0, true>(a, s);
             } else return a.win ? v2_launch1<L, KIND, 0, true, MODE, true>(a, s) : v2_launch1<L, KIND, 0, false, MODE, true>(a, s);
         }
