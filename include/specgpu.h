@@ -163,12 +163,13 @@ void *spec_stream(const spec_ctx *ctx);
  *                     8 TB/s against 0.26 / 0.10 for the four-step team kernel; fp64: cf64 0.37 against 0.32, cf32 -> f64
  *                     0.30 against 0.14); 0 = the four-step paths of "large_team"
  *   "mid_single" = 2 | 1 | 0   16384-point fp32 lines through the same half-line kernel (256-thread workgroups, two per CU):
- *                     2 (default) = where it was measured faster than the family's kernel (without a window: everything but
- *                     cf32 at 75 % / 50 % overlap and ci16 at 75 %, where the family keeps the overlap in registers; with the
- *                     Hann window: big-endian files only), 1 = always, 0 = never
+ *                     2 (default) = in the cells of the GENERATED table csrc/spec_dispatch_table.h (size x format x byte order x
+ *                     hop class x window, measured cell by cell by tools/tune_dispatch.py and re-generated whenever a kernel
+ *                     changes; at the end of round 5 eleven cells, most of them hops other than N, N/2, N/4 -- where the family's
+ *                     kernel has no register-reuse variant -- and hop N without a window), 1 = always, 0 = never
  *   "small_single" = 2 | 1 | 0   8192-point fp32 lines through it (16 points per thread and half, three workgroups per CU):
- *                     2 (default) = cf32 where the family's kernel has no register-reuse variant (big-endian files, hops other
- *                     than N/4, N/2, N; 8 ... 11 points of the roofline faster; level everywhere else), 1 = always, 0 = never
+ *                     2 (default) = by the same table (at the end of round 5 six cells: cf32 at hops other than N, N/2, N/4,
+ *                     either byte order, and two ci8 cells), 1 = always, 0 = never
  *   "coop_256" = 2 | 1 | 0   256-point fp32 lines through the wave-cooperative kernel of the 64- / 128-point lines (a wave reads
  *                     the span of four consecutive lines with 16 bytes per lane into LDS and stores them the same way):
  *                     2 (default) = where it was measured faster than the family's kernel (cu8 / ci8: 1.17x ... 1.46x; cf32 / ci16
