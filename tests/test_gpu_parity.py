@@ -160,6 +160,24 @@ def test_4096_hops_windows(svc, oracle, datatype, window, hop):
     check_fp32(got_g, ref, nfft)
 
 
+@pytest.mark.parametrize("nfft", [512, 1024, 4096])
+@pytest.mark.parametrize("hop_div", [2, 4])
+@pytest.mark.parametrize("window", [sa.WIN_RECT, sa.WIN_HANN])
+@pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be", "ci16_le", "ci16_be"])
+def test_register_reuse_variants_both_byte_orders(svc, oracle, nfft, hop_div, window, datatype):
+    """The family keeps a line's overlap in registers at 50 % and 75 % (spec_v2.h v2_launch_sh): one kernel per (format, byte
+    order, shift, window).  Big-endian files got the windowed and the 75 % ones in round 5 (the raw registers hold the file's
+    bytes, SMH:87-91's swap happens at decode); wave-local lines (512, 1024 points) and whole-workgroup lines (4096), a run long
+    enough for several shifts per sub-line, a start in the middle of the recording."""
+    hop, n_lines = nfft // hop_div, 83
+    iq = oracle.synth_iq(datatype, seed=nfft + hop_div + window, first_sample=5, n_samples=3 + (n_lines - 1) * hop + nfft)
+    start = 3 * oracle.bytes_per_sample(datatype)
+    ref = oracle.waterfall(iq, start, datatype, nfft, hop, n_lines + 1, window)
+    got = svc.compute_waterfall(iq, start, nfft, datatype, n_lines + 1, hop=hop, window=window)
+    assert np.all(got[-1] == -150.0)
+    check_fp32(got[:-1], ref[:-1], nfft)
+
+
 # ---- 32-point-per-thread plans (8192 = 32x16x16, 16384 = 32x32x16): every overlap / window / format variant ----
 @pytest.mark.parametrize("nfft", [8192, 16384])
 @pytest.mark.parametrize("hop_div", [1, 2, 4, 3])          # hop = nfft, nfft/2 (shift E/2), nfft/4 (shift E/4), odd hop
@@ -216,7 +234,7 @@ def _probe_columns(mag, nfft, weakest):
     M = mag.max()
     order = np.argsort(mag)
     weak = order[np.searchsorted(mag[order], weakest * M):][:32]
-    return np.unique(np.concatenate([order[-32:], weak, np.arange(0, nfft, nfft // 128)]))
+    return np.unique(np.concatenate([order[-32:], weak, np.arange(0, nfft, max(1, nfft // 128))]))
 
 
 @pytest.mark.parametrize("nfft", [1024, 4096, 8192, 16384, 32768, 65536])
@@ -239,7 +257,7 @@ def test_fp64_lines_against_a_long_double_dft(svc, oracle, nfft, datatype):
     assert np.abs(20 * np.log10(mag[cols][sel]) - 20 * np.log10(exact[sel])).max() <= 1e-10
 
 
-@pytest.mark.parametrize("nfft", [256, 1024, 4096, 8192, 16384, 32768, 65536])
+@pytest.mark.parametrize("nfft", [64, 128, 256, 1024, 4096, 8192, 16384, 32768, 65536])
 @pytest.mark.parametrize("datatype", ["cf32_le", "ci16_le", "cu8"])
 def test_fp32_lines_against_a_long_double_dft(svc, oracle, nfft, datatype):
     """The twin for the fp32 pipeline (round 5): every fp32 kernel of the default dispatch -- the packed family, the half-line
