@@ -266,6 +266,8 @@ VARIANTS = _unique([
     ("v2qm12", (["-DV2Q_ST_AUX=2", "-DV2Q_M0=1", "-DV2Q_M1=8", "-DV2Q_M2=12"], ["spec_k_v2q.hip"])),
     ("v2qm22", (["-DV2Q_ST_AUX=2", "-DV2Q_M0=2", "-DV2Q_M1=12", "-DV2Q_M2=22"], ["spec_k_v2q.hip"])),
     ("v2qlnt", (["-DV2Q_LD_AUX=2"], ["spec_k_v2q.hip"])),
+    ("v2qroll", (["-DV2Q_ROLLING=1"], ["spec_k_v2q.hip"])),  # the rolling request schedule for every variant (product: with the Hann window only)
+    ("v2qnoroll", (["-DV2Q_ROLLING=0"], ["spec_k_v2q.hip"])),
     # the compiler's own scheduling strategies on the packed family (round 5; -mllvm options of this toolchain)
     ("v2sr", (["-DSPEC_V2_SINGLE_READS=1"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip", "spec_k_v2q.hip", "spec_k_v2n.hip", "spec_k_v2r.hip"])),
     ("schilp", (["-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["spec_k_v2s.hip", "spec_k_v2w.hip", "spec_k_v2h.hip"])),

@@ -131,6 +131,9 @@ template <int J> __device__ __forceinline__ v2f v2q_mul_w128(v2f a) {
 #define V2Q_M1 -1
 #define V2Q_M2 -1
 #endif
+#ifndef V2Q_ROLLING
+#define V2Q_ROLLING 2  // request schedule of the instalments that do not fit (v2q_body): 2 = rolling with the Hann window only, 1 = always, 0 = never
+#endif
 #ifndef V2Q_LD_AUX
 #define V2Q_LD_AUX 0  // sample loads: default policy (every byte is read four times: two workgroups, two lines at 50 % overlap)
 #endif
@@ -219,7 +222,17 @@ __device__ __forceinline__ void v2q_body(const V2qArgs &a, uint32_t line0, uint3
         if constexpr (HAS_WIN) wt64 = wt64s[t];
         v2h_for_each([&](auto m_tag) {
             constexpr int m = decltype(m_tag)::value;
-            if constexpr (m == SPLIT && M2 < E) request_range((int)(line * line_bytes), IM2{}, IE{});  // the registers of the first SPLIT are free
+            // the rest of the line (cf32: the whole line does not fit the registers).  Without a window: all E - M2 instalments at once
+            // at step SPLIT, into the registers of the first SPLIT.  With the Hann window (its fp64 cosines take registers of their
+            // own): one instalment per step into the registers the step before has just freed, M2 in flight all the way -- 119 -> 41
+            // spilled registers, 10.10 -> 7.95 ms on the n65536f shape (0.213 -> 0.270 of 8 TB/s; without a window the rolling
+            // schedule spills 5 and loses 0.8 %: profiles/r05_v2q.txt, variant v2qroll)
+            constexpr bool ROLL = V2Q_ROLLING == 1 || (V2Q_ROLLING == 2 && HAS_WIN);
+            if constexpr (ROLL) {
+                if constexpr (m >= 1 && M2 + m - 1 < E) request((int)(line * line_bytes), std::integral_constant<int, M2 + m - 1>{});
+            } else {
+                if constexpr (m == SPLIT && M2 < E) request_range((int)(line * line_bytes), IM2{}, IE{});
+            }
             v2f x0 = RW::dec(BE ? RW::swap(r[0][m]) : r[0][m]);  // SMH:87-91 byte order
             v2f x2 = RW::dec(BE ? RW::swap(r[2][m]) : r[2][m]);
             v2f x1 = RW::dec(BE ? RW::swap(r[1][m]) : r[1][m]);
