@@ -184,6 +184,34 @@ def live_traffic(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def stream_probe(args, read_bytes: float, write_bytes: float):
+    """What THIS box's memory system delivers for a plain stream with this workload's read : write mix (16-byte coalesced
+    accesses, no arithmetic): tools/membench_rw.hip, built by build() into lib/membench_rw and run as a CHILD process before this
+    process touches the GPU.  HBM3E does not add its directions: on these boxes a read-only stream moves 7.0 TB/s, a write-only
+    one 5.3, 1 : 1 5.5, 1 : 2 (ci16 lines) 4.8, 1 : 4 (cu8) 4.7 -- the ceiling a spectrogram kernel can reach depends on its
+    bytes in per byte out.  Returns a dict or None (never raises; skipped like live_traffic)."""
+    import subprocess
+    if os.environ.get("SPEC_BENCH_CHILD") or "RANK" in os.environ or args.gpus != 1 or args.no_stream_probe:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    exe = os.path.join(ROOT, "spectral_analyzer_amd", "lib", "membench_rw")
+    if not os.path.exists(exe):
+        return None
+    ratio = read_bytes / write_bytes if write_bytes > 0 else float("inf")
+    mix = (4, 0) if ratio > 6 else (2, 1) if ratio >= 1.5 else (2, 2) if ratio >= 0.75 else (1, 2) if ratio >= 0.375 else (1, 4)
+    try:
+        r = subprocess.run([exe, str(mix[0]), str(mix[1])], capture_output=True, text=True, timeout=120)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        if "GBps" not in d:
+            return None
+        d["mix"] = "read %d : write %d (workload: %.2f bytes read per byte written)" % (mix[0], mix[1], ratio) if write_bytes > 0 else "read only"
+        d["how"] = "tools/membench_rw.hip as a child process of this run: 4 GiB in, 4 GiB out, 16-byte non-temporal accesses, best of 8 launches"
+        return d
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def usable_cores() -> int:
     """CPU threads this process may actually run on: affinity mask, capped by a cgroup quota."""
     n = len(os.sched_getaffinity(0))
@@ -245,6 +273,7 @@ def main() -> None:
     ap.add_argument("--log2-samples", type=int, default=None, help="override samples per GPU (debug)")
     ap.add_argument("--n-psd", type=int, default=None, help="cfg4: PSDs per GPU and step (default 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-probe", action="store_true", help="skip roofline.stream (the box's plain-stream ceiling for the workload's read : write mix)")
     ap.add_argument("--no-live-traffic", action="store_true", help="report the stamped traffic figure instead of measuring it (two rocprofv3 child runs)")
     ap.add_argument("--gather-steps", type=int, default=3, help="N > 1: steps of the compute+gather timing")
     ap.add_argument("--gather-chunks", type=int, default=8)
@@ -263,6 +292,10 @@ def main() -> None:
         args.workload = "cfg2"
     # BEFORE anything touches the GPU: the counter passes run as children of this process
     live_bytes, live_note = (None, "--no-live-traffic") if args.no_live_traffic else live_traffic(args)
+    _w = WORKLOADS[args.workload]
+    _bps_in = {"cf32_le": 8, "ci16_le": 4, "cf64_le": 16}[_w["datatype"]]
+    stream_ceiling = stream_probe(args, float(_w["hop"] * _bps_in),
+                          0.0 if _w["kind"] == "welch" else float(_w["nfft"] * (8 if _w.get("out") == "f64" else 4)))
     # SPEC_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a ONE-GPU box -- every rank on device 0,
     # gloo instead of RCCL (which refuses two ranks on one device).  Never used by the driver.
     rehearse = os.environ.get("SPEC_BENCH_REHEARSE") == "1"
@@ -471,7 +504,9 @@ def main() -> None:
                     # extras: reads only (the north star is phrased on reads) and the box's own copy rate
                     "read_frac": n_lines * hop * bps / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "copy_GBps": copy_gbps,
-                    "frac_of_copy": (achieved / copy_gbps) if copy_gbps else None}
+                    "frac_of_copy": (achieved / copy_gbps) if copy_gbps else None,
+                    # the box's own ceiling for a plain stream of this read : write mix, measured in this run (stream_probe)
+                    "stream": dict(stream_ceiling, frac_of_stream=achieved / stream_ceiling["GBps"]) if stream_ceiling else None}
             metric = ("spectrogram lines/sec (4096-pt FFT, 50% overlap)" if nfft == 4096 else
                       "spectrogram lines/sec (%d-pt FFT, %d %% overlap)" % (nfft, round(100 * (1 - hop / nfft))))
             workload = "%s: %d-pt FFT, hop %d, %s, 2^%d samples per GPU, %d lines total, %s out" % (

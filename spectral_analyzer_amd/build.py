@@ -290,6 +290,24 @@ VARIANTS = _unique([
 ])
 
 
+STREAM_PROBE = os.path.join(LIBDIR, "membench_rw")
+
+
+def build_tools(verbose: bool = False) -> str:
+    """tools/membench_rw.hip -> lib/membench_rw: the stand-alone stream probe bench.py runs as a child process (the box's own
+    ceiling for a workload's read : write mix, roofline.stream).  A measurement aid, not part of the library."""
+    src = os.path.join(HERE, "..", "tools", "membench_rw.hip")
+    if os.path.exists(STREAM_PROBE) and os.path.getmtime(STREAM_PROBE) >= os.path.getmtime(src):
+        return STREAM_PROBE
+    os.makedirs(LIBDIR, exist_ok=True)
+    r = subprocess.run([_hipcc(), "-O3", "--offload-arch=" + ARCH, src, "-o", STREAM_PROBE], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on tools/membench_rw.hip:\n%s" % r.stderr[-2000:])
+    if verbose:
+        print("built", STREAM_PROBE)
+    return STREAM_PROBE
+
+
 def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=(), only=None) -> str:
     """Build the product library, or -- ``variant`` -- an EXPERIMENT library beside it
     (lib/libspecgpu_<variant>.so, objects under build/<variant>/, compiled with ``extra_flags``, e.g. the
