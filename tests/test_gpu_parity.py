@@ -465,6 +465,22 @@ def test_short_lines_many_blocks_per_wave(svc, oracle, coop, nfft, datatype, hop
         check_fp32(got[lo:lo + (1 << 16)], ref[lo:lo + (1 << 16)], nfft, regression=False)
 
 
+def test_coop_256_knob_every_value(svc, oracle):
+    """ "coop_256" (include/specgpu.h): 0 = the family's kernel, 1 = the cooperative kernel, 2 = by the measured rule -- a cu8 line
+    (rule: cooperative) and a cf32 line at 50 % overlap (rule: family) through every value, all against the oracle; the option reads
+    back what was set and ends at its default."""
+    try:
+        for datatype, hop in (("cu8", 128), ("cf32_le", 128), ("ci16_be", 100)):
+            iq = oracle.synth_iq(datatype, seed=77, first_sample=0, n_samples=49 * hop + 256)
+            ref = oracle.waterfall(iq, 0, datatype, 256, hop, 50)
+            for knob in (0, 1, 2):
+                svc.set_option("coop_256", knob)
+                assert svc.get_option("coop_256") == knob
+                check_fp32(svc.compute_waterfall(iq, 0, 256, datatype, 50, hop=hop), ref, 256)
+    finally:
+        svc.set_option("coop_256", 2)
+
+
 @pytest.mark.parametrize("datatype", ["cf32_le", "cf32_be"])
 @pytest.mark.parametrize("nfft", [64, 128, 256])
 def test_short_lines_start_at_4_mod_8(svc, oracle, coop, nfft, datatype):
