@@ -859,6 +859,14 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                                                     : (rem + sub * c->n_cu * 8 - 1) / (sub * c->n_cu * 8);
             if (run < 1) run = 1;
             if (run > 32) run = 32;
+            // Without an overlap to keep in registers (the reference's own hop = nfft, MC:984-985) a long run buys nothing, and short
+            // ones let neighbouring workgroups work on neighbouring lines: 1024 / 2048 / 4096 points +2 ... +9 % with runs of 8 / 4 / 4
+            // (cf32 and ci16, two sweeps on one box: tools/bench_run_len.py, profiles/r05_run_len.txt; 256 / 512 points and the
+            // 32-point-per-thread sizes are level or mixed and keep the long runs)
+            if (c->opt_lines_per_wg <= 0 && hop >= nfft && log2n >= 10 && log2n <= 12) {
+                const uint64_t cap = log2n == 10 ? 8 : 4;
+                if (run > cap) run = cap;
+            }
             // 32-bit byte offsets inside a workgroup's span (input and output side)
             while (run > 1 && sub * run * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;
             const uint64_t max_lines = 0x7FFFFFFFull;  // 32-bit line index inside one launch
