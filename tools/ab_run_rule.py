@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""A/B of run lengths by alternating measurements on one box: `ab_run_rule.py hopn` -- runs of 32 against the automatic rule at
+hop = nfft (1024 / 2048 / 4096 points, three recording sizes); `ab_run_rule.py half K...` -- runs of 32 against runs of K at 50 %
+overlap (256 ... 4096 points).  Fractions of 8 TB/s."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import spectral_analyzer_amd as sa
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
@@ -12,17 +16,19 @@ def timeit(fn, reps=12, warm=8):
         a.record(st); fn(); b.record(st); ev.append((a, b))
     torch.cuda.synchronize()
     return float(np.median([a.elapsed_time(b) for a, b in ev]))
+mode = sys.argv[1] if len(sys.argv) > 1 else "hopn"
+ks = [int(x) for x in sys.argv[2:]] or [0]
 for dt in ("cf32_le", "ci16_le"):
-  for nfft in (1024, 2048, 4096):
-    for lg in (26, 28, 30):
-        S = 1 << lg; hop = nfft; n = S // hop; bps = sa.bytes_per_sample(dt)
+  for nfft in ((1024, 2048, 4096) if mode == "hopn" else (256, 512, 1024, 2048, 4096)):
+    for lg in ((26, 28, 30) if mode == "hopn" else (28, 30)):
+        S = 1 << lg; hop = nfft if mode == "hopn" else nfft // 2; n = (S - nfft) // hop + 1; bps = sa.bytes_per_sample(dt)
         iq = svc.synth_iq(dt, 7, 0, S); out = torch.empty((n, nfft), dtype=torch.float32, device="cuda")
-        res = []
+        res = {}
         for rep in range(2):
-            for k in (32, 0):
+            for k in [32] + ks:
                 svc.set_option("lines_per_wg", k)
                 ms = timeit(lambda: svc.compute_waterfall(iq, 0, nfft, dt, n, hop=hop, out=out))
-                res.append(n * (hop * bps + nfft * 4) / ms / 1e6 / 8000)
+                res.setdefault(k, []).append(n * (hop * bps + nfft * 4) / ms / 1e6 / 8000)
         svc.set_option("lines_per_wg", 0)
-        print("%-8s n=%d 2^%d samples: runs of 32: %.3f %.3f   rule: %.3f %.3f" % (dt, nfft, lg, res[0], res[2], res[1], res[3]), flush=True)
+        print("%-8s n=%-5d hop=%-5d 2^%d samples: " % (dt, nfft, hop, lg) + "   ".join("%s: %.3f %.3f" % ("rule" if k == 0 else "runs of %d" % k, *res[k]) for k in [32] + ks), flush=True)
         del iq, out; torch.cuda.empty_cache()
