@@ -820,6 +820,7 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             a.n_lines = rem < 0x40000000ull ? rem : 0x40000000ull;
             a.iq = d_first + done * (uint64_t)hop * a.bps;
             a.out = static_cast<uint8_t *>(d_out) + done * nfft * out_esz;
+            a.lines_per_wg = c->opt_lines_per_wg > 0 ? (uint32_t)c->opt_lines_per_wg : 0;  // here: consecutive BLOCKS per wave and chunk
             hipError_t e = launch_v2n_spectro(a, log2n, c->n_cu, c->stream);
             if (e != hipSuccess) return fail(c, SPEC_EDEVICE, "spectrogram launch: %s", hipGetErrorString(e));
             done += a.n_lines;

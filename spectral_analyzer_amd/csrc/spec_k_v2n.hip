@@ -26,6 +26,7 @@ struct V2nArgs {
     uint32_t n_lines, hop;
     uint32_t pad_shift;  // floor(log2(hop * BPS)): one pad unit per 2^pad_shift bytes of span
     uint32_t in_bytes;   // v2n_dma_kernel: bytes of a wave's landing buffer for this call's hop
+    uint32_t chunk;      // v2n_dma_kernel: consecutive blocks a wave takes before it jumps gridDim.x chunks ahead (0: automatic = 4; "lines_per_wg" sets it)
     const void *tw, *win;
     float *out;
     int out_fmt;
@@ -218,8 +219,14 @@ __global__ __launch_bounds__(64, V2N_OCC) void v2n_dma_kernel(const V2nArgs a) {
     }
     const uint32_t n_blocks = (a.n_lines + LB - 1) / LB;
     const uint32_t per_wave = (n_blocks + gridDim.x - 1) / gridDim.x;
-    const uint32_t b0 = blockIdx.x * per_wave, b1 = b0 + per_wave < n_blocks ? b0 + per_wave : n_blocks;
+    // this wave's blocks: chunks of `chunk` consecutive blocks, gridDim.x chunks apart.  All of a wave's blocks in ONE piece (rounds
+    // 1-5: the samples two blocks share come back from L2) spreads the waves that run together over the whole recording; chunks of 4
+    // keep them on neighbouring blocks: +3 ... +8 % at 64 / 128 points and for the 256-point cells of this kernel, at hop = nfft and
+    // at 50 % overlap, 2^28 and 2^30 samples (tools/bench_coop_chunk.py, profiles/r05_run_len.txt; chunks of 1 lose, 2 ... 8 are close)
+    const uint32_t want = a.chunk ? a.chunk : 4u, chunk = want < per_wave ? want : per_wave, jump = (gridDim.x - 1) * chunk;
+    const uint32_t b0 = blockIdx.x * chunk, b1 = n_blocks;
     if (b0 >= b1) return;
+    auto next_block = [&](uint32_t b) -> uint32_t { return (b + 1) % chunk ? b + 1 : b + 1 + jump; };
     const uint32_t line_bytes = a.hop * BPS, psh = a.pad_shift;  // psh >= 8 (the launcher's condition)
     auto padded = [&](uint32_t x) -> uint32_t { return x + (x >> psh) * (uint32_t)PADU; };
     const uint32_t landing_lds = v2n_lds_addr(landing);
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(64, V2N_OCC) void v2n_dma_kernel(const V2nArgs a) {
     };
     request(b0);
     bool full_prev = false;  // the previous block issued STORES output stores behind this block's request
-    for (uint32_t b = b0; b < b1; ++b) {
+    for (uint32_t b = b0; b < b1; b = next_block(b)) {
         const uint32_t l0 = b * LB;
         const uint32_t nb = a.n_lines - l0 < (uint32_t)LB ? a.n_lines - l0 : (uint32_t)LB;
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(a.iq + (uint64_t)l0 * line_bytes) & 3u);
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(64, V2N_OCC) void v2n_dma_kernel(const V2nArgs a) {
             else r = *reinterpret_cast<const uint16_t *>(p);
             v[m] = RW::dec(BE ? RW::swap(r) : r);  // SMH:87-91 byte order
         }
-        if (b + 1 < b1) request(b + 1);  // (its lgkmcnt(0): the picks above have been read)
+        if (next_block(b) < b1) request(next_block(b));  // (its lgkmcnt(0): the picks above have been read)
         if (win) {
 #pragma unroll
             for (int m = 0; m < E; ++m) v[m] *= v2f{w[m], w[m]};
@@ -371,6 +378,7 @@ hipError_t launch_v2n_spectro(const WfArgs &w, int log2n, int n_cu, hipStream_t 
     V2nArgs a{};
     a.iq = w.iq; a.n_lines = (uint32_t)w.n_lines; a.hop = w.hop; a.tw = w.tw; a.win = w.win;
     a.out = static_cast<float *>(w.out); a.out_fmt = w.out_fmt;
+    a.chunk = w.lines_per_wg;  // (blocks; 0 = automatic)
     uint32_t lb = w.hop * w.bps, sh = 0;
     while ((2u << sh) <= lb) ++sh;
     a.pad_shift = sh;
