@@ -840,6 +840,13 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
                                                     : (rem + sub * c->n_cu * 8 - 1) / (sub * c->n_cu * 8);
             if (run < 1) run = 1;
             if (run > 32) run = 32;
+            // (as for the fp32 family below: without an overlap short runs keep neighbouring workgroups on neighbouring lines --
+            // cf64 lines of 1024 / 2048 points +10 % / +9 % with runs of 4, 4096 points +2 % with 8; cf32 / ci16 -> f64 lines are
+            // bound by their arithmetic and level: profiles/r05_run_len.txt)
+            if (c->opt_lines_per_wg <= 0 && hop >= nfft && log2n >= 10 && log2n <= 12) {
+                const uint64_t cap = log2n == 12 ? 8 : 4;
+                if (run > cap) run = cap;
+            }
             while (run > 1 && sub * run * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;
             a.n_lines = rem < 0x7FFFFFFFull ? rem : 0x7FFFFFFFull;
             a.iq = d_first + done * (uint64_t)hop * a.bps;
