@@ -878,6 +878,8 @@ static spec_status run_lines(spec_ctx *c, const uint8_t *d_first, spec_dtype dt,
             // (with 50 % overlap long runs are right -- each run start re-reads half a line -- except for cf32 lines of 256 and 1024
             // points: runs of 16 there, +6 ... +12 % and +3 ... +5 %; ci16 and the other sizes are level or lose: same log)
             if (c->opt_lines_per_wg <= 0 && hop * 2 == (uint32_t)nfft && a.kind == K_CF32 && (log2n == 8 || log2n == 10) && run > 16) run = 16;
+            // (and cf32 lines of 512 points at hop = nfft: runs of 16, +1.5 ... +6 % at 2^26 ... 2^30 samples; 256 points and ci16 are mixed)
+            if (c->opt_lines_per_wg <= 0 && hop >= nfft && a.kind == K_CF32 && log2n == 9 && run > 16) run = 16;
             // 32-bit byte offsets inside a workgroup's span (input and output side)
             while (run > 1 && sub * run * ((uint64_t)hop * a.bps + nfft * out_esz) >= (1ull << 31)) run /= 2;
             const uint64_t max_lines = 0x7FFFFFFFull;  // 32-bit line index inside one launch

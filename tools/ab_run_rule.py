@@ -20,7 +20,7 @@ F64 = os.environ.get("AB_F64") == "1"   # the fp64 pipeline (cf64 / ci16 in, DB2
 mode = sys.argv[1] if len(sys.argv) > 1 else "hopn"
 ks = [int(x) for x in sys.argv[2:]] or [0]
 for dt in (("cf64_le", "ci16_le") if F64 else ("cf32_le", "ci16_le")):
-  for nfft in ((1024, 2048, 4096) if mode == "hopn" else (256, 512, 1024, 2048, 4096)):
+  for nfft in ([int(x) for x in os.environ["AB_SIZES"].split(",")] if os.environ.get("AB_SIZES") else (1024, 2048, 4096) if mode == "hopn" else (256, 512, 1024, 2048, 4096)):
     for lg in ((28,) if F64 else (26, 28, 30) if mode == "hopn" else (28, 30)):
         S = 1 << lg; hop = nfft if mode == "hopn" else nfft // 2; n = (S - nfft) // hop + 1; bps = sa.bytes_per_sample(dt)
         iq = svc.synth_iq(dt, 7, 0, S); out = torch.empty((n, nfft), dtype=torch.float64 if F64 else torch.float32, device="cuda")
